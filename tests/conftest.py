@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: long-running CPU test')
+
+
+def golden_cases():
+    return sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith('.json'))
+
+
+def load_golden(name):
+    import json
+    with open(os.path.join(GOLDEN_DIR, name + '.json')) as f:
+        return json.load(f)
+
+
+@pytest.fixture
+def single_thread():
+    import torch
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)

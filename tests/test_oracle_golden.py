@@ -1,0 +1,114 @@
+"""The CPU oracle (oracle/sagan_cpu.py) against fixtures produced by the
+reference's own code (tests/golden/make_golden.py).  This is what pins the
+oracle; the HIP path is then compared with the oracle / the same fixtures."""
+import copy
+
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+from oracle import sagan_cpu as O
+from oracle.procedural import procedural_state, summarize, synthetic_images
+
+FAST = [c for c in golden_cases() if not c.endswith('b64')]
+SLOW = [c for c in golden_cases() if c.endswith('b64')]
+
+
+def _close(a, b, rel=2e-5, abs_=1e-7):
+    return abs(a - b) <= abs_ + rel * max(abs(a), abs(b))
+
+
+def _check_summary(t, ref, rel=2e-5, what=''):
+    got = summarize(t, len(ref['idx']))
+    assert got['numel'] == ref['numel'], what
+    assert _close(got['l2'], ref['l2'], rel), (what, got['l2'], ref['l2'])
+    scale = max(ref['max_abs'], 1e-12)
+    for g, r in zip(got['samples'], ref['samples']):
+        assert abs(g - r) <= rel * scale * 4 + 1e-9, (what, g, r)
+
+
+def _total_l2(S, grads=False):
+    s = 0.
+    for k, v in S.items():
+        if O.is_param(k):
+            t = v.grad if grads else v
+            if t is not None:
+                s += float(t.detach().double().pow(2).sum())
+    return s ** 0.5
+
+
+def _run(case):
+    fx = load_golden(case)
+    torch.manual_seed(0)
+    tr = O.OracleTrainer(fx['config'], fx['trainer'], fx['batch'], attention=fx['attention'])
+    # state_dict key parity with the reference modules
+    assert list(tr.g.keys()) == fx['state_keys']['g']
+    assert list(tr.d.keys()) == fx['state_keys']['d']
+    # default-init parity (same seed => same initial parameters)
+    di = fx['default_init']
+    assert _close(_total_l2(tr.g), di['g_l2'], 1e-6)
+    assert _close(_total_l2(tr.target_g), di['target_g_l2'], 1e-6)
+    assert _close(_total_l2(tr.d), di['d_l2'], 1e-6)
+    _check_summary(next(v for k, v in tr.g.items() if O.is_param(k)), di['g_first'], 1e-6, 'g_first')
+    _check_summary([v for k, v in tr.d.items() if O.is_param(k)][-1], di['d_last'], 1e-6, 'd_last')
+    assert sum(v.numel() for k, v in tr.g.items() if O.is_param(k)) == fx['n_params']['g']
+    assert sum(v.numel() for k, v in tr.d.items() if O.is_param(k)) == fx['n_params']['d']
+
+    tr.load(g=procedural_state(tr.g, fx['weight_seed']),
+            target_g=procedural_state(tr.target_g, fx['weight_seed'] + 1),
+            d=procedural_state(tr.d, fx['weight_seed'] + 2))
+    # forward pins
+    with torch.no_grad():
+        g2, d2 = copy.deepcopy(tr.g), copy.deepcopy(tr.d)
+        z = torch.randn(fx['batch'], tr.cfg.latent_dims, generator=torch.Generator().manual_seed(99))
+        imgs0 = synthetic_images(fx['batch'], fx['size'], fx['img_seed'])
+        g_out = O.g_forward(g2, z, tr.cfg)
+        _check_summary(g_out, fx['forward']['g_out'], 1e-5, 'g_out')
+        if fx['trainer'] == 'cnn':
+            d_real = O.d_forward(d2, imgs0, tr.cfg)
+            d_fake = O.d_forward(d2, g_out, tr.cfg)
+            for a, b in zip(d_fake.reshape(-1).tolist(), fx['forward']['d_fake']):
+                assert _close(a, b, 1e-5, 1e-5)
+        else:
+            torch.manual_seed(555)
+            d_real, loss = O.iqn_d_forward(d2, imgs0, tr.cfg, targets=torch.ones(fx['batch'], 1))
+            assert _close(float(loss), fx['forward']['d_real_loss'], 1e-5)
+            torch.manual_seed(555)
+            taus = O.sample_taus(fx['batch'])
+            assert taus.reshape(-1)[:8].tolist() == fx['forward']['taus_head']   # bit-exact
+        for a, b in zip(d_real.reshape(-1).tolist(), fx['forward']['d_real']):
+            assert _close(a, b, 1e-5, 1e-5)
+        _check_summary(O.g_forward(g2, z, tr.cfg, training=False), fx['forward']['g_out_eval'], 1e-5, 'g_eval')
+
+    torch.manual_seed(fx['rng_seed'])
+    for k, ref in enumerate(fx['steps']):
+        logs = tr.train_batch(synthetic_images(fx['batch'], fx['size'], fx['img_seed'] + k))
+        for name in ('g_loss', 'd_loss', 'gp'):
+            assert _close(logs[name], ref[name], 2e-5), (case, k, name, logs[name], ref[name])
+        assert _close(_total_l2(tr.g), ref['g_l2'], 1e-5)
+        assert _close(_total_l2(tr.d), ref['d_l2'], 1e-5)
+        assert _close(_total_l2(tr.target_g), ref['target_g_l2'], 1e-5)
+        assert _close(_total_l2(tr.g, True), ref['g_grad_l2'], 1e-4)
+        assert _close(_total_l2(tr.d, True), ref['d_grad_l2'], 1e-4)
+        if k == 0:
+            for name, ref_s in fx['after_step1']['d_grad'].items():
+                _check_summary(tr.d[name].grad, ref_s, 1e-4, 'd_grad ' + name)
+            for name, ref_s in fx['after_step1']['g_grad'].items():
+                _check_summary(tr.g[name].grad, ref_s, 1e-4, 'g_grad ' + name)
+    for net in ('g', 'd', 'target_g'):
+        S = getattr(tr, net)
+        for name, ref_s in fx['final'][net].items():
+            _check_summary(S[name], ref_s, 1e-4, f'final {net} {name}')
+    # RNG stream consumed exactly like the reference (z / tau draw order)
+    assert float(torch.rand(1)) == fx['rng_after']
+
+
+@pytest.mark.parametrize('case', FAST)
+def test_oracle_matches_reference_fixture(case, single_thread):
+    _run(case)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize('case', SLOW)
+def test_oracle_matches_reference_fixture_full_batch(case, single_thread):
+    _run(case)
