@@ -1,0 +1,184 @@
+/*
+ * tartangan_amd.h -- C ABI of libtartangan_amd.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary for tartangan's SA-GAN / SA-GAN-IQN G+D training step
+ * (SURVEY.md §8b).  The reference has no native code: every entry point below
+ * replaces the ATen op(s) that the cited reference line dispatches through
+ * torch.nn / torch.nn.functional.  Paths are relative to
+ * /root/reference/tartangan.
+ *
+ * Conventions
+ *   - all tensors fp32, contiguous, NCHW (the reference's layout); raw device
+ *     pointers; the caller owns every byte including workspaces;
+ *   - enqueue-only on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream); no allocation, no synchronisation, graph-capture safe;
+ *   - return 0 on success, a negative TG_E* code for a bad argument or an
+ *     unsupported shape, a positive value = hipError_t from the launch;
+ *   - re-entrant; no mutable global state.
+ */
+#ifndef TARTANGAN_AMD_H
+#define TARTANGAN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_OK 0
+#define TG_EINVAL (-1)      /* null pointer / non-positive dimension */
+#define TG_EUNSUPPORTED (-2) /* shape outside what the kernels implement */
+#define TG_EWORKSPACE (-3)  /* workspace too small */
+
+/* library / build identification */
+int tg_version(void);
+const char* tg_arch(void);
+
+/* ---------------------------------------------------------------- convolution
+ * nn.Conv2d(k=3,pad=1) / nn.Conv2d(k=1): models/blocks/generator.py:41,44,52,124
+ * models/blocks/discriminator.py:17,63,66,78  models/blocks/attention.py:14-17
+ * ks in {1,3}, stride 1, zero pad ks/2.  w is OIHW [Cout][Cin][ks][ks].        */
+int tg_conv2d_fwd(const float* x, const float* w, const float* bias /*nullable*/, float* y,
+                  int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+/* gx = d/dx: correlation of gy with the transposed, spatially flipped filter
+ * (what autograd's convolution_backward computes for grad_input)              */
+int tg_conv2d_dgrad(const float* gy, const float* w, float* gx,
+                    int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+/* gw[co][ci][kh][kw] = sum_{b,h,w} gy[b,co,h,w] * x[b,ci,h+kh-p,w+kw-p]
+ * (convolution_backward grad_weight); deterministic two-stage reduction.      */
+size_t tg_conv2d_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ks);
+int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* workspace, size_t workspace_bytes,
+                    int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+/* out[c] = sum_{b,p} x[b][c][p]   (conv bias grad; torch.sum(feats,[2,3]) with B*C rows) */
+int tg_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
+/* out[b][c][p] = v[c] (transpose of tg_channel_sum) */
+int tg_channel_bcast(const float* v, float* out, int B, int C, int HW, void* stream);
+
+/* ---------------------------------------------------------------- GEMM
+ * nn.Linear (generator.py:70-72, discriminator.py:137-139,158-160, iqn.py:33-35)
+ * and torch.bmm (attention.py:32,34).  Row-major; C[b] = op(A[b]) op(B[b]) (+ bias[n]).
+ * op(A) is MxK, op(B) is KxN; lda/ldb/ldc are row strides of the stored arrays. */
+int tg_gemm(const float* A, const float* Bm, float* C, const float* bias_n /*nullable*/,
+            int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
+            int batch, int64_t strideA, int64_t strideB, int64_t strideC, void* stream);
+
+/* ---------------------------------------------------------------- BatchNorm2d (+LeakyReLU)
+ * nn.BatchNorm2d train mode followed by nn.LeakyReLU(0.2): generator.py:38-44,
+ * discriminator.py:60-66,133-136,153-156.  slope = 1 gives plain BatchNorm.
+ * Workspace: tg_bn_workspace(C) bytes.                                         */
+size_t tg_bn_workspace(int B, int C, int HW);
+/* batch mean / 1/sqrt(biased var + eps); optional running-stat update
+ * (running_var uses the unbiased variance, momentum as nn.BatchNorm2d)         */
+int tg_bn_train_stats(const float* x, float* mean, float* invstd,
+                      float* running_mean /*nullable*/, float* running_var /*nullable*/,
+                      float momentum, float eps, float* workspace, int B, int C, int HW, void* stream);
+/* eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps) */
+int tg_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd,
+                     float eps, int C, void* stream);
+/* z = lrelu(gamma * (x - mean) * invstd + beta, slope) */
+int tg_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, float slope, float* z, int B, int C, int HW, void* stream);
+/* first backward (native_batch_norm_backward o leaky_relu_backward):
+ * gyh = gz * lrelu'(y); ggamma = sum gyh*xhat; gbeta = sum gyh;
+ * training: gx = gamma*invstd*(gyh - mean(gyh) - xhat*mean(gyh*xhat)); eval: gx = gamma*invstd*gyh */
+int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const float* invstd,
+                  const float* gamma, const float* beta, float slope, int training,
+                  float* gx /*nullable*/, float* ggamma, float* gbeta, float* workspace,
+                  int B, int C, int HW, void* stream);
+/* second backward of the training-mode map (gz, x, gamma) -> (gx, ggamma, gbeta)
+ * (NativeBatchNormBackwardBackward0; R1 penalty path, models/losses.py:23-26).
+ * v = adjoint of gx, vgamma/vbeta = adjoints of ggamma/gbeta (nullable = 0).   */
+int tg_bn_act_dbwd(const float* v, const float* vgamma /*nullable*/, const float* vbeta /*nullable*/,
+                   const float* gz, const float* x, const float* mean, const float* invstd,
+                   const float* gamma, const float* beta, float slope,
+                   float* adj_gz, float* adj_x, float* adj_gamma, float* workspace,
+                   int B, int C, int HW, void* stream);
+
+/* ---------------------------------------------------------------- resampling
+ * F.interpolate(scale_factor=2,'nearest') generator.py:58 and nn.AvgPool2d(2)
+ * discriminator.py:67 are transposes of each other up to a factor:
+ *   up2x : y[2h+i][2w+j] = alpha * x[h][w]       pool2: y[h][w] = alpha * sum_{i,j} x[2h+i][2w+j]
+ * (nearest fwd = up2x(1), bwd = pool2(1); avgpool fwd = pool2(.25), bwd = up2x(.25)).
+ * H, W are the dims of the SMALL side for up2x (output 2H x 2W) and of the LARGE
+ * (input) side for pool2; both must be even for pool2.                          */
+int tg_up2x(const float* x, float* y, float alpha, int BC, int H, int W, void* stream);
+int tg_pool2(const float* x, float* y, float alpha, int BC, int H, int W, void* stream);
+/* F.interpolate(scale_factor=0.5, mode='bilinear', align_corners=True) discriminator.py:55-57
+ * input HxW -> output floor(H/2) x floor(W/2); _bwd is its transpose (scatter-free gather form) */
+int tg_bilinear_half_fwd(const float* x, float* y, int BC, int H, int W, void* stream);
+int tg_bilinear_half_bwd(const float* gy, float* gx, int BC, int H, int W, void* stream);
+/* F.max_pool2d(x,[2,2]) attention.py:25-26; idx = argmax position 0..3 inside the window
+ * (first maximum in row-major window order, like ATen)                          */
+int tg_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int BC, int H, int W, void* stream);
+/* gx[window(o)[idx[o]]] = gy[o], zeros elsewhere (H,W = dims of gx) */
+int tg_maxpool2_bwd(const float* gy, const uint8_t* idx, float* gx, int BC, int H, int W, void* stream);
+/* y[o] = x[window(o)[idx[o]]] (transpose of _bwd; H,W = dims of x) */
+int tg_maxpool2_gather(const float* x, const uint8_t* idx, float* y, int BC, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- row ops
+ * out[r] = alpha * sum_c x[r][c]  (torch.sum(feats,[2,3]) discriminator.py:143,165) */
+int tg_row_sum(const float* x, float* out, float alpha, int rows, int cols, void* stream);
+/* out[r][c] = alpha * v[r] */
+int tg_row_bcast(const float* v, float* out, float alpha, int rows, int cols, void* stream);
+/* x.repeat(reps,1) (iqn.py:93): out[q*rows + r][c] = alpha * x[r][c]            */
+int tg_repeat_rows(const float* x, float* out, float alpha, int rows, int cols, int reps, void* stream);
+/* out[r][c] = alpha * sum_q x[q*rows + r][c]  (p_target_tau.mean(0), discriminator.py:174-175) */
+int tg_sum_reps(const float* x, float* out, float alpha, int rows, int cols, int reps, void* stream);
+
+/* ---------------------------------------------------------------- elementwise */
+int tg_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+int tg_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
+int tg_scale(const float* x, float alpha, float* out, int64_t n, void* stream);
+/* out = (alpha * *s) * x, s a device scalar */
+int tg_scale_dev(const float* s, float alpha, const float* x, float* out, int64_t n, void* stream);
+/* out = *s * a + b  (gamma * o + x, attention.py:35) */
+int tg_scale_add_dev(const float* s, const float* a, const float* b, float* out, int64_t n, void* stream);
+/* *out = alpha * sum_i a[i]*b[i]  (deterministic two-stage; workspace tg_reduce_workspace(n)) */
+size_t tg_reduce_workspace(int64_t n);
+int tg_dot(const float* a, const float* b, float alpha, float* out, float* workspace, int64_t n, void* stream);
+/* out = g * (x >= 0 ? 1 : slope)  (LeakyReLU fwd when g == x; leaky_relu_backward otherwise) */
+int tg_lrelu_bwd(const float* g, const float* x, float slope, float* out, int64_t n, void* stream);
+int tg_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
+/* out = g * (1 - y*y) */
+int tg_tanh_bwd(const float* g, const float* y, float* out, int64_t n, void* stream);
+int tg_fill(float* x, float value, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------- softmax (attention.py:32) */
+int tg_softmax_fwd(const float* s, float* y, int rows, int cols, void* stream);
+/* gs = y * (gy - sum(gy*y)) */
+int tg_softmax_bwd(const float* gy, const float* y, float* gs, int rows, int cols, void* stream);
+/* adjoint of y in gs = softmax_bwd(gy, y) given v = adjoint of gs:
+ * out = v*gy - v*sum(gy*y) - gy*sum(v*y)                                        */
+int tg_softmax_dbwd(const float* v, const float* gy, const float* y, float* out, int rows, int cols, void* stream);
+
+/* ---------------------------------------------------------------- IQN head (models/iqn.py)
+ * out[i][j] = cos((taus[i] * pi) * range[j])   iqn.py:41-45 (fp32, this evaluation order) */
+int tg_iqn_cos_embed(const float* taus, const float* range, float* out, int n, int dims, void* stream);
+/* iqn.py:111-130: preds (Q*B), row = q*B + b; target (B); taus (Q*B).
+ * *loss = sum_q,b |tau - 1[err<0]| * huber_k(err) / B ; dpreds = d loss / d preds       */
+int tg_iqn_loss(const float* preds, const float* target, const float* taus, float k,
+                float* loss, float* dpreds, float* workspace, int Q, int B, void* stream);
+
+/* ---------------------------------------------------------------- losses
+ * nn.BCEWithLogitsLoss (mean) trainers/cnn.py:88,131,147; dlogits = (sigmoid(x)-t)/n    */
+int tg_bce_logits(const float* logits, const float* targets, float* loss, float* dlogits,
+                  float* workspace, int n, void* stream);
+/* *out = alpha * sum x^2  (R1: grad.pow(2).view(B,-1).sum(1).mean(), losses.py:27-29)   */
+int tg_sumsq(const float* x, float alpha, float* out, float* workspace, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------- optimiser / EMA
+ * torch.optim.Adam (trainers/cnn.py:84-85), single flat tensor.
+ * hyper (device, 4 floats): [lr/bias_correction1, sqrt(bias_correction2), beta1, beta2]
+ * so the captured graph is step-independent:
+ *   m = lerp(m, g, 1-beta1); v = beta2*v + (1-beta2)*g*g;
+ *   p -= hyper[0] * m / (sqrt(v)/hyper[1] + eps)                                        */
+int tg_adam_step(float* p, const float* g, float* m, float* v, const float* hyper, float eps,
+                 int64_t n, void* stream);
+/* update_target_generator (trainers/cnn.py:158-165): t += (p - t) * lr */
+int tg_ema(float* t, const float* p, float lr, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TARTANGAN_AMD_H */

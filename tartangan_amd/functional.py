@@ -1,0 +1,831 @@
+"""Autograd glue over the C ABI (include/tartangan_amd.h).
+
+Every differentiable op of the SA-GAN / SA-GAN-IQN step is a
+``torch.autograd.Function`` whose ``backward`` is itself written with
+``Function.apply`` calls, so the R1 penalty's ``autograd.grad(...,
+create_graph=True)`` followed by ``d_loss.backward()`` (reference
+models/losses.py:17-30, trainers/cnn.py:133-136) differentiates twice through
+hand-written HIP kernels only.  PyTorch supplies tensor storage and graph
+bookkeeping, nothing else.
+
+Linear ops come as transpose pairs (each is the other's backward):
+  conv2d fwd <-> dgrad, (wgrad bilinear);  up2x <-> pool2;  bilinear_half <-> its
+  transpose;  maxpool scatter <-> gather;  row_sum <-> row_bcast;
+  repeat_rows <-> sum_reps;  channel_sum <-> channel_bcast.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import backend as _be
+
+
+def K():
+    return _be.get()
+
+
+def _ws(like, nbytes):
+    return torch.empty(max(1, (int(nbytes) + 3) // 4), dtype=torch.float32, device=like.device)
+
+
+# =========================================================================== conv
+class _ConvFwd(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, w = x.contiguous(), w.contiguous()
+        B, Cin, H, W = x.shape
+        Cout, ks = w.shape[0], w.shape[2]
+        y = x.new_empty(B, Cout, H, W)
+        K().conv2d_fwd(x, w, bias, y, B, Cin, Cout, H, W, ks)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _ConvDgrad.apply(gy, w)
+        if ctx.needs_input_grad[1]:
+            gw = _ConvWgrad.apply(x, gy, w.shape[2])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _ChannelSum.apply(gy)
+        return gx, gw, gb
+
+
+class _ConvDgrad(Function):
+    @staticmethod
+    def forward(ctx, gy, w):
+        gy, w = gy.contiguous(), w.contiguous()
+        B, Cout, H, W = gy.shape
+        Cin, ks = w.shape[1], w.shape[2]
+        gx = gy.new_empty(B, Cin, H, W)
+        K().conv2d_dgrad(gy, w, gx, B, Cin, Cout, H, W, ks)
+        ctx.save_for_backward(gy, w)
+        return gx
+
+    @staticmethod
+    def backward(ctx, v):
+        gy, w = ctx.saved_tensors
+        v = v.contiguous()
+        a_gy = a_w = None
+        if ctx.needs_input_grad[0]:
+            a_gy = _ConvFwd.apply(v, w, None)
+        if ctx.needs_input_grad[1]:
+            a_w = _ConvWgrad.apply(v, gy, w.shape[2])
+        return a_gy, a_w
+
+
+class _ConvWgrad(Function):
+    @staticmethod
+    def forward(ctx, x, gy, ks):
+        x, gy = x.contiguous(), gy.contiguous()
+        B, Cin, H, W = x.shape
+        Cout = gy.shape[1]
+        gw = x.new_empty(Cout, Cin, ks, ks)
+        nbytes = K().conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks)
+        ws = _ws(x, nbytes)
+        K().conv2d_wgrad(x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks)
+        ctx.save_for_backward(x, gy)
+        return gw
+
+    @staticmethod
+    def backward(ctx, vw):
+        x, gy = ctx.saved_tensors
+        vw = vw.contiguous()
+        a_x = a_gy = None
+        if ctx.needs_input_grad[0]:
+            a_x = _ConvDgrad.apply(gy, vw)
+        if ctx.needs_input_grad[1]:
+            a_gy = _ConvFwd.apply(x, vw, None)
+        return a_x, a_gy, None
+
+
+class _ChannelSum(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        hw = x[0, 0].numel()
+        out = x.new_empty(C)
+        K().channel_sum(x, out, B, C, hw)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, v):
+        return _ChannelBcast.apply(v, ctx.shape)
+
+
+class _ChannelBcast(Function):
+    @staticmethod
+    def forward(ctx, v, shape):
+        v = v.contiguous()
+        out = v.new_empty(shape)
+        hw = 1
+        for s in shape[2:]:
+            hw *= s
+        K().channel_bcast(v, out, shape[0], shape[1], hw)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ChannelSum.apply(g), None
+
+
+def conv2d(x, weight, bias=None):
+    """3x3 (pad 1) or 1x1 (pad 0) stride-1 convolution, NCHW fp32."""
+    return _ConvFwd.apply(x, weight, bias)
+
+
+# =========================================================================== GEMM
+class _Gemm(Function):
+    """C = op(A) op(B); A,B 2-D or batched 3-D row-major."""
+
+    @staticmethod
+    def forward(ctx, A, Bm, ta, tb):
+        A, Bm = A.contiguous(), Bm.contiguous()
+        batch = A.shape[0] if A.dim() == 3 else 1
+        ar, ac = A.shape[-2], A.shape[-1]
+        br, bc = Bm.shape[-2], Bm.shape[-1]
+        M, Kd = (ac, ar) if ta else (ar, ac)
+        Kb, N = (bc, br) if tb else (br, bc)
+        assert Kd == Kb, (A.shape, Bm.shape, ta, tb)
+        shape = (batch, M, N) if A.dim() == 3 else (M, N)
+        C = A.new_empty(shape)
+        K().gemm(A, Bm, C, None, M, N, Kd, ac, bc, N, int(ta), int(tb), batch,
+                 ar * ac, br * bc, M * N)
+        ctx.save_for_backward(A, Bm)
+        ctx.ta, ctx.tb = ta, tb
+        return C
+
+    @staticmethod
+    def backward(ctx, g):
+        A, Bm = ctx.saved_tensors
+        ta, tb = ctx.ta, ctx.tb
+        gA = gB = None
+        if ctx.needs_input_grad[0]:
+            gA = _Gemm.apply(Bm, g, tb, True) if ta else _Gemm.apply(g, Bm, False, not tb)
+        if ctx.needs_input_grad[1]:
+            gB = _Gemm.apply(g, A, True, ta) if tb else _Gemm.apply(A, g, not ta, False)
+        return gA, gB, None, None
+
+
+def matmul(A, Bm, transA=False, transB=False):
+    return _Gemm.apply(A, Bm, transA, transB)
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        x, w = x.contiguous(), w.contiguous()
+        M, Kd = x.shape
+        N = w.shape[0]
+        y = x.new_empty(M, N)
+        K().gemm(x, w, y, bias, M, N, Kd, Kd, Kd, N, 0, 1, 1, 0, 0, 0)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _Gemm.apply(gy, w, False, False)
+        if ctx.needs_input_grad[1]:
+            gw = _Gemm.apply(gy, x, True, False)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _ChannelSum.apply(gy)
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    return _Linear.apply(x, weight, bias)
+
+
+# =========================================================================== BatchNorm (+LeakyReLU)
+class _BNAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        hw = x[0, 0].numel()
+        mean, invstd = x.new_empty(C), x.new_empty(C)
+        if training:
+            ws = _ws(x, K().bn_workspace(B, C, hw))
+            K().bn_train_stats(x, mean, invstd, running_mean, running_var, float(momentum), float(eps),
+                               ws, B, C, hw)
+        else:
+            K().bn_eval_stats(running_mean, running_var, mean, invstd, float(eps), C)
+        z = torch.empty_like(x)
+        K().bn_act_fwd(x, mean, invstd, gamma, beta, float(slope), z, B, C, hw)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.training, ctx.slope = bool(training), float(slope)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        gx, gg, gb = _BNActBwd.apply(gz, x, gamma, beta, mean, invstd, ctx.slope, ctx.training,
+                                     ctx.needs_input_grad[0])
+        return gx, gg, gb, None, None, None, None, None, None
+
+
+class _BNActBwd(Function):
+    @staticmethod
+    def forward(ctx, gz, x, gamma, beta, mean, invstd, slope, training, need_gx=True):
+        gz = gz.contiguous()
+        B, C = x.shape[0], x.shape[1]
+        hw = x[0, 0].numel()
+        gx = torch.empty_like(x) if need_gx else None
+        gg, gb = x.new_empty(C), x.new_empty(C)
+        ws = _ws(x, K().bn_workspace(B, C, hw))
+        K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, slope, int(training), gx, gg, gb, ws, B, C, hw)
+        ctx.save_for_backward(gz, x, gamma, beta, mean, invstd)
+        ctx.slope, ctx.training = slope, training
+        return gx, gg, gb
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, v, vg, vb):
+        if not ctx.training:
+            raise NotImplementedError('double backward through eval-mode BatchNorm is not implemented')
+        gz, x, gamma, beta, mean, invstd = ctx.saved_tensors
+        B, C = x.shape[0], x.shape[1]
+        hw = x[0, 0].numel()
+        a_gz, a_x = torch.empty_like(x), torch.empty_like(x)
+        a_gamma = x.new_empty(C)
+        ws = _ws(x, K().bn_workspace(B, C, hw))
+        K().bn_act_dbwd(v.contiguous(), vg.contiguous(), vb.contiguous(), gz, x, mean, invstd, gamma, beta,
+                        ctx.slope, a_gz, a_x, a_gamma, ws, B, C, hw)
+        return a_gz, a_x, a_gamma, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, slope=1.0):
+    """BatchNorm2d followed by LeakyReLU(slope) in one pass (slope=1: plain BN)."""
+    return _BNAct.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, slope)
+
+
+# =========================================================================== resampling
+class _Up2x(Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = x.new_empty(B, C, 2 * H, 2 * W)
+        K().up2x(x, y, alpha, B * C, H, W)
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Pool2.apply(g, ctx.alpha), None
+
+
+class _Pool2(Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        if H % 2 or W % 2:
+            raise RuntimeError('pool2 needs even spatial dims')
+        y = x.new_empty(B, C, H // 2, W // 2)
+        K().pool2(x, y, alpha, B * C, H, W)
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Up2x.apply(g, ctx.alpha), None
+
+
+def upsample_nearest2x(x):
+    return _Up2x.apply(x, 1.0)
+
+
+def avg_pool2(x):
+    return _Pool2.apply(x, 0.25)
+
+
+class _BilinearHalf(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = x.new_empty(B, C, H // 2, W // 2)
+        K().bilinear_half_fwd(x, y, B * C, H, W)
+        ctx.hw = (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return _BilinearHalfT.apply(g, ctx.hw)
+
+
+class _BilinearHalfT(Function):
+    @staticmethod
+    def forward(ctx, gy, hw):
+        gy = gy.contiguous()
+        B, C = gy.shape[:2]
+        gx = gy.new_empty(B, C, hw[0], hw[1])
+        K().bilinear_half_bwd(gy, gx, B * C, hw[0], hw[1])
+        return gx
+
+    @staticmethod
+    def backward(ctx, v):
+        return _BilinearHalf.apply(v), None
+
+
+def bilinear_half(x):
+    """F.interpolate(x, scale_factor=0.5, mode='bilinear', align_corners=True)"""
+    return _BilinearHalf.apply(x)
+
+
+class _MaxPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = x.new_empty(B, C, H // 2, W // 2)
+        idx = torch.empty(B, C, H // 2, W // 2, dtype=torch.uint8, device=x.device)
+        K().maxpool2_fwd(x, y, idx, B * C, H, W)
+        ctx.save_for_backward(idx)
+        ctx.hw = (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        return _MaxPoolScatter.apply(g, idx, ctx.hw)
+
+
+class _MaxPoolScatter(Function):
+    @staticmethod
+    def forward(ctx, gy, idx, hw):
+        gy = gy.contiguous()
+        B, C = gy.shape[:2]
+        gx = gy.new_empty(B, C, hw[0], hw[1])
+        K().maxpool2_bwd(gy, idx, gx, B * C, hw[0], hw[1])
+        ctx.save_for_backward(idx)
+        ctx.hw = hw
+        return gx
+
+    @staticmethod
+    def backward(ctx, v):
+        idx, = ctx.saved_tensors
+        return _MaxPoolGather.apply(v, idx), None, None
+
+
+class _MaxPoolGather(Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = x.new_empty(B, C, H // 2, W // 2)
+        K().maxpool2_gather(x, idx, y, B * C, H, W)
+        ctx.save_for_backward(idx)
+        ctx.hw = (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        return _MaxPoolScatter.apply(g, idx, ctx.hw), None
+
+
+def max_pool2(x):
+    return _MaxPool2.apply(x)
+
+
+# =========================================================================== row ops
+class _RowSum(Function):
+    """(..., H, W) -> (...) * alpha over the trailing ``nd`` dims."""
+
+    @staticmethod
+    def forward(ctx, x, nd, alpha):
+        x = x.contiguous()
+        lead, tail = x.shape[:-nd], x.shape[-nd:]
+        cols = 1
+        for s in tail:
+            cols *= s
+        rows = x.numel() // cols
+        out = x.new_empty(lead)
+        K().row_sum(x, out, alpha, rows, cols)
+        ctx.tail, ctx.alpha = tuple(tail), alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _RowBcast.apply(g, ctx.tail, ctx.alpha), None, None
+
+
+class _RowBcast(Function):
+    @staticmethod
+    def forward(ctx, v, tail, alpha):
+        v = v.contiguous()
+        out = v.new_empty(tuple(v.shape) + tuple(tail))
+        cols = 1
+        for s in tail:
+            cols *= s
+        K().row_bcast(v, out, alpha, v.numel(), cols)
+        ctx.nd, ctx.alpha = len(tail), alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _RowSum.apply(g, ctx.nd, ctx.alpha), None, None
+
+
+def sum_hw(x):
+    """torch.sum(x, [2, 3])"""
+    return _RowSum.apply(x, 2, 1.0)
+
+
+class _RepeatRows(Function):
+    @staticmethod
+    def forward(ctx, x, reps, alpha):
+        x = x.contiguous()
+        rows, cols = x.shape
+        out = x.new_empty(rows * reps, cols)
+        K().repeat_rows(x, out, alpha, rows, cols, reps)
+        ctx.reps, ctx.alpha = reps, alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _SumReps.apply(g, ctx.reps, ctx.alpha), None, None
+
+
+class _SumReps(Function):
+    @staticmethod
+    def forward(ctx, x, reps, alpha):
+        x = x.contiguous()
+        rows, cols = x.shape[0] // reps, x.shape[1]
+        out = x.new_empty(rows, cols)
+        K().sum_reps(x, out, alpha, rows, cols, reps)
+        ctx.reps, ctx.alpha = reps, alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _RepeatRows.apply(g, ctx.reps, ctx.alpha), None, None
+
+
+def repeat_rows(x, reps):
+    """x.repeat(reps, 1)"""
+    return _RepeatRows.apply(x, reps, 1.0)
+
+
+def mean_reps(x, reps):
+    """x.reshape(reps, -1, cols).mean(0)"""
+    return _SumReps.apply(x, reps, 1.0 / reps)
+
+
+# =========================================================================== elementwise
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        K().add(a, b, out, a.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Mul(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        K().mul(a, b, out, a.numel())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = _Mul.apply(g, b) if ctx.needs_input_grad[0] else None
+        gb = _Mul.apply(g, a) if ctx.needs_input_grad[1] else None
+        return ga, gb
+
+
+def mul(a, b):
+    return _Mul.apply(a, b)
+
+
+class _Scale(Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        K().scale(x, alpha, out, x.numel())
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Scale.apply(g, ctx.alpha), None
+
+
+def scale(x, alpha):
+    return _Scale.apply(x, float(alpha))
+
+
+class _ScaleDev(Function):
+    """(alpha * s) * x with s a 0-d device tensor."""
+
+    @staticmethod
+    def forward(ctx, s, x, alpha):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        K().scale_dev(s, alpha, x, out, x.numel())
+        ctx.save_for_backward(s, x)
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s, x = ctx.saved_tensors
+        gs = _Dot.apply(g, x, ctx.alpha).reshape(s.shape) if ctx.needs_input_grad[0] else None
+        gx = _ScaleDev.apply(s, g, ctx.alpha) if ctx.needs_input_grad[1] else None
+        return gs, gx, None
+
+
+class _Dot(Function):
+    """alpha * sum(a*b) as a 0-d tensor."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, b = a.contiguous(), b.contiguous()
+        out = a.new_empty(())
+        ws = _ws(a, K().reduce_workspace(a.numel()))
+        K().dot(a, b, alpha, out, ws, a.numel())
+        ctx.save_for_backward(a, b)
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga = _ScaleDev.apply(g, b, ctx.alpha) if ctx.needs_input_grad[0] else None
+        gb = _ScaleDev.apply(g, a, ctx.alpha) if ctx.needs_input_grad[1] else None
+        return ga, gb, None
+
+
+class _ScaleAddDev(Function):
+    """s * a + b  (attention.py:35: gamma * o + x)"""
+
+    @staticmethod
+    def forward(ctx, s, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        K().scale_add_dev(s, a, b, out, a.numel())
+        ctx.save_for_backward(s, a)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s, a = ctx.saved_tensors
+        gs = _Dot.apply(g, a, 1.0).reshape(s.shape) if ctx.needs_input_grad[0] else None
+        ga = _ScaleDev.apply(s, g, 1.0) if ctx.needs_input_grad[1] else None
+        return gs, ga, g
+
+
+def scale_add(s, a, b):
+    return _ScaleAddDev.apply(s, a, b)
+
+
+class _LReluBwd(Function):
+    """g * lrelu'(x); LeakyReLU forward is the case g is x."""
+
+    @staticmethod
+    def forward(ctx, g, x, slope):
+        g, x = g.contiguous(), x.contiguous()
+        out = torch.empty_like(x)
+        K().lrelu_bwd(g, x, slope, out, x.numel())
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return out
+
+    @staticmethod
+    def backward(ctx, v):
+        x, = ctx.saved_tensors
+        return _LReluBwd.apply(v, x, ctx.slope), None, None
+
+
+class _LRelu(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        K().lrelu_bwd(x, x, slope, out, x.numel())
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return _LReluBwd.apply(g, x, ctx.slope), None
+
+
+def leaky_relu(x, slope=0.2):
+    return _LRelu.apply(x, float(slope))
+
+
+class _Tanh(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        K().tanh_fwd(x, y, x.numel())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        return _TanhBwd.apply(g, y)
+
+
+class _TanhBwd(Function):
+    @staticmethod
+    def forward(ctx, g, y):
+        g, y = g.contiguous(), y.contiguous()
+        out = torch.empty_like(y)
+        K().tanh_bwd(g, y, out, y.numel())
+        ctx.save_for_backward(g, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, v):
+        g, y = ctx.saved_tensors
+        a_g = _TanhBwd.apply(v, y) if ctx.needs_input_grad[0] else None
+        a_y = None
+        if ctx.needs_input_grad[1]:
+            a_y = _Scale.apply(_Mul.apply(_Mul.apply(v, g), y), -2.0)
+        return a_g, a_y
+
+
+def tanh(x):
+    return _Tanh.apply(x)
+
+
+# =========================================================================== softmax
+class _Softmax(Function):
+    @staticmethod
+    def forward(ctx, s):
+        s = s.contiguous()
+        cols = s.shape[-1]
+        y = torch.empty_like(s)
+        K().softmax_fwd(s, y, s.numel() // cols, cols)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, = ctx.saved_tensors
+        return _SoftmaxBwd.apply(gy, y)
+
+
+class _SoftmaxBwd(Function):
+    @staticmethod
+    def forward(ctx, gy, y):
+        gy, y = gy.contiguous(), y.contiguous()
+        cols = y.shape[-1]
+        gs = torch.empty_like(y)
+        K().softmax_bwd(gy, y, gs, y.numel() // cols, cols)
+        ctx.save_for_backward(gy, y)
+        return gs
+
+    @staticmethod
+    def backward(ctx, v):
+        gy, y = ctx.saved_tensors
+        a_gy = _SoftmaxBwd.apply(v, y) if ctx.needs_input_grad[0] else None
+        a_y = None
+        if ctx.needs_input_grad[1]:
+            a_y = _SoftmaxDbwdY.apply(v, gy, y)
+        return a_gy, a_y
+
+
+class _SoftmaxDbwdY(Function):
+    @staticmethod
+    def forward(ctx, v, gy, y):
+        v = v.contiguous()
+        cols = y.shape[-1]
+        out = torch.empty_like(y)
+        K().softmax_dbwd(v, gy, y, out, y.numel() // cols, cols)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        raise NotImplementedError('third-order softmax derivative')
+
+
+def softmax_lastdim(s):
+    return _Softmax.apply(s)
+
+
+# =========================================================================== IQN / losses
+def iqn_cos_embed(taus, embedding_range):
+    """cos((tau*pi)*range) -- no gradient (taus are sampled, range is a buffer)."""
+    taus = taus.contiguous()
+    n, dims = taus.shape[0], embedding_range.shape[0]
+    out = taus.new_empty(n, dims)
+    K().iqn_cos_embed(taus, embedding_range, out, n, dims)
+    return out
+
+
+class _ScaledGrad(Function):
+    """Common backward of the scalar losses: d loss / d preds was produced by
+    the forward kernel; the backward only scales it by the upstream scalar."""
+
+    @staticmethod
+    def _finish(ctx, preds, dpreds):
+        ctx.save_for_backward(dpreds)
+        ctx.shape = preds.shape
+
+    @staticmethod
+    def _bwd(ctx, g):
+        dpreds, = ctx.saved_tensors
+        out = torch.empty_like(dpreds)
+        K().scale_dev(g.contiguous(), 1.0, dpreds, out, dpreds.numel())
+        return out.view(ctx.shape)
+
+
+class _IQNLoss(Function):
+    @staticmethod
+    def forward(ctx, preds, target, taus, num_quantiles, k):
+        pc, target, taus = preds.contiguous(), target.contiguous(), taus.contiguous()
+        B = target.shape[0]
+        loss = pc.new_empty(())
+        dpreds = torch.empty_like(pc)
+        ws = _ws(pc, K().reduce_workspace(pc.numel()))
+        K().iqn_loss(pc, target, taus, float(k), loss, dpreds, ws, num_quantiles, B)
+        _ScaledGrad._finish(ctx, preds, dpreds)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return _ScaledGrad._bwd(ctx, g), None, None, None, None
+
+
+def iqn_quantile_huber_loss(preds, target, taus, num_quantiles, k=1.0):
+    """models/iqn.py:111-130 for out_dims == 1 (preds/taus (Q*B,1), row = q*B + b)."""
+    return _IQNLoss.apply(preds, target, taus, num_quantiles, k)
+
+
+class _BCELogits(Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        lc, targets = logits.contiguous(), targets.contiguous()
+        loss = lc.new_empty(())
+        dl = torch.empty_like(lc)
+        ws = _ws(lc, K().reduce_workspace(lc.numel()))
+        K().bce_logits(lc, targets, loss, dl, ws, lc.numel())
+        _ScaledGrad._finish(ctx, logits, dl)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return _ScaledGrad._bwd(ctx, g), None
+
+
+def bce_with_logits(logits, targets):
+    """nn.BCEWithLogitsLoss() (mean reduction)."""
+    return _BCELogits.apply(logits, targets)
+
+
+class _SumSq(Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = x.contiguous()
+        out = x.new_empty(())
+        ws = _ws(x, K().reduce_workspace(x.numel()))
+        K().sumsq(x, alpha, out, ws, x.numel())
+        ctx.save_for_backward(x)
+        ctx.alpha = alpha
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return _ScaleDev.apply(g.contiguous(), x, 2.0 * ctx.alpha), None
+
+
+def sumsq(x, alpha=1.0):
+    return _SumSq.apply(x, float(alpha))

@@ -1,0 +1,98 @@
+"""Discriminator blocks of the reference (models/blocks/discriminator.py) on HIP kernels.
+
+Implemented: ``DiscriminatorInput`` (discriminator.py:11-22),
+``ResidualDiscriminatorBlock`` (:49-95), ``DiscriminatorOutput`` (:126-146),
+``IQNDiscriminatorOutput`` (:149-178).  Every op here is differentiable twice
+(the real-image branch sits under the R1 penalty).
+"""
+import functools
+
+from torch import nn
+
+from ... import functional as TF
+from ..iqn import IQN, iqn_loss
+from ..layers import AvgPool2d, BatchNorm2d, Conv2d, LeakyReLU, Linear, interpolate, run_layers
+
+_lrelu = functools.partial(LeakyReLU, 0.2)
+_half = functools.partial(interpolate, scale_factor=0.5, mode='bilinear', align_corners=True)
+
+
+class DiscriminatorInput(nn.Module):
+    """from-RGB 1x1 convolution"""
+
+    def __init__(self, in_dims, out_dims, conv_factory=Conv2d, activation_factory=_lrelu):
+        super().__init__()
+        self.convs = nn.Sequential(conv_factory(in_dims, out_dims, 1, padding=0, bias=True))
+
+    def forward(self, img):
+        return run_layers(self.convs, img)
+
+
+class ResidualDiscriminatorBlock(nn.Module):
+    """[norm, act,] conv3x3, norm, act, conv3x3, avgpool2  +  bilinear-half(x) [-> conv1x1]"""
+
+    def __init__(self, in_dims, out_dims, first_block=False, norm_factory=BatchNorm2d,
+                 conv_factory=Conv2d, avg_pool_factory=AvgPool2d, activation_factory=_lrelu,
+                 interpolate=_half):
+        super().__init__()
+        body = []
+        if not first_block:
+            body += [norm_factory(in_dims), activation_factory()]
+        body += [conv_factory(in_dims, out_dims, 3, padding=1, bias=True),
+                 norm_factory(out_dims), activation_factory(),
+                 conv_factory(out_dims, out_dims, 3, padding=1, bias=True),
+                 avg_pool_factory(2)]
+        self.convs = nn.Sequential(*body)
+        self.in_dims = in_dims
+        self.out_dims = out_dims
+        self.project_input = None
+        if in_dims != out_dims:
+            self.project_input = nn.Sequential(conv_factory(in_dims, out_dims, 1))
+        self.interpolate = interpolate
+
+    def forward(self, x):
+        h = run_layers(self.convs, x)
+        x = self.interpolate(x)
+        if self.project_input is not None:
+            x = run_layers(self.project_input, x)
+        return TF.add(x, h)
+
+
+class DiscriminatorOutput(nn.Module):
+    """norm -> act -> sum over (H, W) -> Linear"""
+
+    def __init__(self, in_dims, out_dims, norm_factory=BatchNorm2d, activation_factory=_lrelu,
+                 output_activation_factory=nn.Identity):
+        super().__init__()
+        self.activation = nn.Sequential(norm_factory(in_dims), activation_factory())
+        self.to_output = nn.Sequential(Linear(in_dims, out_dims), output_activation_factory())
+
+    def forward(self, feats):
+        feats = TF.sum_hw(run_layers(self.activation, feats))
+        return run_layers(self.to_output, feats)
+
+
+class IQNDiscriminatorOutput(nn.Module):
+    """norm -> act -> sum pool -> IQN quantile mixing -> Linear; returns the quantile
+    mean and, when targets are given, the quantile Huber loss."""
+
+    def __init__(self, in_dims, out_dims, norm_factory=BatchNorm2d, activation_factory=_lrelu):
+        super().__init__()
+        self.activation = nn.Sequential(norm_factory(in_dims), activation_factory())
+        self.to_output = nn.Sequential(Linear(in_dims, out_dims))
+        self.iqn = IQN(in_dims)
+        self.out_dims = out_dims
+
+    def forward(self, feats, targets=None):
+        feats = TF.sum_hw(run_layers(self.activation, feats))
+        feats_tau, taus = self.iqn(feats)
+        p_target_tau = run_layers(self.to_output, feats_tau)
+        loss = None
+        if targets is not None:
+            if self.out_dims != 1:
+                raise NotImplementedError('IQN loss kernel covers out_dims == 1 (the trainers\' case)')
+            loss = iqn_loss(p_target_tau, targets, taus)
+        p_target = TF.mean_reps(p_target_tau, self.iqn.num_quantiles)
+        if targets is not None:
+            return p_target, loss
+        return p_target

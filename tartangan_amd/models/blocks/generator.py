@@ -1,0 +1,85 @@
+"""Generator blocks of the reference (models/blocks/generator.py) on HIP kernels.
+
+Only the classes trainers.cnn / trainers.iqn instantiate are implemented:
+``ResidualGeneratorBlock`` (generator.py:32-62), ``GeneratorInputMLP`` (:65-80),
+``TiledZGeneratorInput`` (:101-112, the --g-base tiledz variant) and
+``GeneratorOutput`` (:115-129).  Constructor signatures, sub-module names and
+registration order follow the reference so state_dicts interchange.
+"""
+import functools
+
+from torch import nn
+
+from ... import functional as TF
+from ..layers import BatchNorm2d, Conv2d, LeakyReLU, Linear, Tanh, run_layers
+
+_lrelu = functools.partial(LeakyReLU, 0.2)
+
+
+class ResidualGeneratorBlock(nn.Module):
+    """up x2 (nearest) -> [norm, act,] conv3x3, norm, act, conv3x3, plus the upsampled
+    input (through a 1x1 projection when the width changes)."""
+
+    def __init__(self, in_dims, out_dims, upsample=True, first_block=False,
+                 norm_factory=BatchNorm2d, conv_factory=Conv2d, activation_factory=_lrelu):
+        super().__init__()
+        body = []
+        if not first_block:
+            body += [norm_factory(in_dims), activation_factory()]
+        body += [conv_factory(in_dims, out_dims, 3, padding=1),
+                 norm_factory(out_dims), activation_factory(),
+                 conv_factory(out_dims, out_dims, 3, padding=1)]
+        self.upsample = upsample
+        self.project_input = None
+        if in_dims != out_dims:
+            self.project_input = nn.Sequential(conv_factory(in_dims, out_dims, 1))
+        self.convs = nn.Sequential(*body)
+
+    def forward(self, x):
+        if self.upsample:
+            x = TF.upsample_nearest2x(x)
+        h = run_layers(self.convs, x)
+        if self.project_input is not None:
+            x = run_layers(self.project_input, x)
+        return TF.add(x, h)
+
+
+class GeneratorInputMLP(nn.Module):
+    """z -> Linear -> act -> (B, C0, size, size)"""
+
+    def __init__(self, latent_dims, output_dims, size=4, norm_factory=None, activation_factory=_lrelu):
+        super().__init__()
+        self.base_img = nn.Sequential(Linear(latent_dims, size ** 2 * output_dims), activation_factory())
+        self.latent_dims = latent_dims
+        self.output_dims = output_dims
+        self.size = size
+
+    def forward(self, z):
+        return run_layers(self.base_img, z).view(-1, self.output_dims, self.size, self.size)
+
+
+class TiledZGeneratorInput(nn.Module):
+    """z tiled over a size x size grid (needs latent_dims == output_dims)."""
+
+    def __init__(self, latent_dims, output_dims, size=4, norm_factory=None, **_):
+        super().__init__()
+        self.size = size
+        assert latent_dims == output_dims
+
+    def forward(self, z):
+        return TF._RowBcast.apply(z, (self.size, self.size), 1.0)
+
+
+class GeneratorOutput(nn.Module):
+    """norm -> act -> conv1x1 -> tanh"""
+
+    def __init__(self, in_dims, out_dims, norm_factory=BatchNorm2d, conv_factory=Conv2d,
+                 activation_factory=_lrelu, output_activation_factory=Tanh):
+        super().__init__()
+        self.convs = nn.Sequential(
+            norm_factory(in_dims), activation_factory(),
+            conv_factory(in_dims, out_dims, 1, padding=0, bias=True),
+            output_activation_factory())
+
+    def forward(self, x):
+        return run_layers(self.convs, x)

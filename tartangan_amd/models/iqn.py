@@ -1,0 +1,58 @@
+"""IQN pieces of the reference (models/iqn.py) on HIP kernels.
+
+``CosineQuantileEmbedding`` (iqn.py:27-46), ``IQN`` (:76-108) and ``iqn_loss``
+(:111-130).  Quantile fractions tau are drawn from the CPU default generator and
+then moved to the device exactly like the reference (:105-108), so a seed gives
+the same taus on any device; rows are quantile-major (row = q * B + b).
+"""
+import torch
+from torch import nn
+
+from .. import functional as TF
+from .layers import Linear, Tanh, run_layers
+
+
+class CosineQuantileEmbedding(nn.Module):
+    def __init__(self, state_dims, embedding_dims=64, activation=Tanh, norm_factory=None):
+        super().__init__()
+        self.embedding_dims = embedding_dims
+        self.to_state = nn.Sequential(Linear(embedding_dims, state_dims), activation())
+        self.register_buffer('embedding_range', torch.arange(1, embedding_dims + 1).float())
+
+    def forward(self, quantiles):
+        return run_layers(self.to_state, TF.iqn_cos_embed(quantiles, self.embedding_range))
+
+
+class IQN(nn.Module):
+    def __init__(self, feature_dims, quantile_dims=20, num_quantiles=8, mix='mult',
+                 quantile_embedding_factory=CosineQuantileEmbedding, norm_factory=None):
+        super().__init__()
+        self.quantile_embedding = quantile_embedding_factory(feature_dims, quantile_dims,
+                                                             norm_factory=norm_factory)
+        self.feature_dims = feature_dims
+        self.num_quantiles = num_quantiles
+        self.mix = mix
+        self._device = None
+
+    def forward(self, x):
+        batch_size = x.shape[0]
+        x = TF.repeat_rows(x, self.num_quantiles)               # (Q*B, C), row = q*B + b
+        quantiles = self.sample_quantiles(batch_size)           # (Q*B, 1)
+        emb = self.quantile_embedding(quantiles)
+        if self.mix == 'add':
+            return TF.add(x, emb), quantiles
+        elif self.mix.startswith('mult'):
+            return TF.mul(x, emb), quantiles
+        raise ValueError(f'Unknown mix method {self.mix}')
+
+    def sample_quantiles(self, n=1):
+        if self._device is None:
+            self._device = next(self.parameters()).device
+        return torch.rand(n * self.num_quantiles, 1).to(self._device)
+
+
+def iqn_loss(preds, target, taus, k=1.):
+    assert not target.requires_grad
+    batch_size = target.shape[0]
+    num_quantiles = preds.shape[0] // batch_size
+    return TF.iqn_quantile_huber_loss(preds, target.reshape(batch_size, -1), taus, num_quantiles, k)

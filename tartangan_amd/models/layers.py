@@ -1,0 +1,129 @@
+"""HIP-backed layer modules.
+
+The reference's ``models/layers.py:6-22`` holds ``Interpolate`` and
+``PixelNorm``; the reference blocks otherwise take stock ``torch.nn`` layers
+through their ``norm_factory`` / ``conv_factory`` / ``activation_factory`` /
+``avg_pool_factory`` hooks (models/blocks/discriminator.py:50-58,
+generator.py:33-35).  The classes here are what this package plugs into those
+hooks: same constructor signatures, same parameters / buffers / state_dict
+keys and the same default initialisation (they subclass the torch modules and
+only replace ``forward``), but the arithmetic runs in libtartangan_amd.so.
+"""
+import functools
+
+import torch
+from torch import nn
+
+from .. import functional as TF
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d restricted to what the hot path uses: 3x3/pad 1 or 1x1/pad 0, stride 1."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding=0, bias=True, **kw):
+        super().__init__(in_channels, out_channels, kernel_size, padding=padding, bias=bias, **kw)
+        ks = self.kernel_size
+        ok = (ks in ((1, 1), (3, 3)) and self.padding == (ks[0] // 2, ks[0] // 2)
+              and self.stride == (1, 1) and self.dilation == (1, 1) and self.groups == 1)
+        if not ok:
+            raise ValueError(f'tartangan_amd.Conv2d supports 3x3/pad1 and 1x1/pad0 stride-1 only, got {self}')
+
+    def forward(self, x):
+        return TF.conv2d(x, self.weight, self.bias)
+
+
+class Linear(nn.Linear):
+    def forward(self, x):
+        return TF.linear(x, self.weight, self.bias)
+
+
+class LeakyReLU(nn.LeakyReLU):
+    def forward(self, x):
+        return TF.leaky_relu(x, self.negative_slope)
+
+
+class Tanh(nn.Tanh):
+    def forward(self, x):
+        return TF.tanh(x)
+
+
+class AvgPool2d(nn.AvgPool2d):
+    def __init__(self, kernel_size, **kw):
+        super().__init__(kernel_size, **kw)
+        if kernel_size not in (2, (2, 2)):
+            raise ValueError('tartangan_amd.AvgPool2d supports kernel_size=2 only')
+
+    def forward(self, x):
+        return TF.avg_pool2(x)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """Train-mode batch statistics or eval-mode running statistics; ``forward_act``
+    fuses the LeakyReLU that follows it in every reference block."""
+
+    def _run(self, x, slope):
+        if self.momentum is None or not self.affine or not self.track_running_stats:
+            raise NotImplementedError('tartangan_amd.BatchNorm2d: default nn.BatchNorm2d options only')
+        training = self.training
+        if training:
+            self.num_batches_tracked.add_(1)
+        return TF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
+                                 training, self.momentum, self.eps, slope)
+
+    def forward(self, x):
+        return self._run(x, 1.0)
+
+    def forward_act(self, x, slope):
+        return self._run(x, slope)
+
+
+def run_layers(seq, x):
+    """Apply an ``nn.Sequential`` the way ``Sequential.forward`` would, fusing each
+    (BatchNorm2d, LeakyReLU) pair into one kernel pass."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if (isinstance(m, BatchNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], LeakyReLU)):
+            x = m.forward_act(x, mods[i + 1].negative_slope)
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
+class Interpolate(nn.Module):
+    """models/layers.py:6-14 for the two resamplings the hot path uses."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.args = args
+        self.kwargs = kwargs
+
+    def forward(self, x):
+        return interpolate(x, *self.args, **self.kwargs)
+
+
+def interpolate(x, size=None, scale_factor=None, mode='nearest', align_corners=None):
+    """F.interpolate for (scale 2, nearest) and (scale .5, bilinear, align_corners=True)."""
+    if size is None and scale_factor == 2 and mode == 'nearest':
+        return TF.upsample_nearest2x(x)
+    if size is None and scale_factor == 0.5 and mode == 'bilinear' and align_corners:
+        return TF.bilinear_half(x)
+    raise NotImplementedError(f'interpolate(scale_factor={scale_factor}, mode={mode}, '
+                              f'align_corners={align_corners}) is outside the hot path')
+
+
+class PixelNorm(nn.Module):
+    """models/layers.py:17-22 -- not on the cnn/iqn hot path; kept for API parity."""
+
+    def __init__(self, eps=1e-8):
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, x):
+        raise NotImplementedError('PixelNorm is not used by trainers.cnn / trainers.iqn')
+
+
+default_activation = functools.partial(LeakyReLU, 0.2)

@@ -1,0 +1,100 @@
+"""Flat-buffer Adam and EMA for the G+D step.
+
+The reference steps ``torch.optim.Adam(betas=(0., 0.999))`` over 32-59 small
+tensors per network and updates the EMA ("target") generator tensor by tensor
+(trainers/cnn.py:84-85,158-165): some 300 tiny launches per step.  Here every
+network's parameters live in ONE contiguous fp32 buffer (the ``nn.Parameter``s
+are views into it, their ``.grad``s views into a twin buffer), so Adam is one
+elementwise kernel, the EMA is one kernel, ``zero_grad`` is one fill and a
+data-parallel gradient all-reduce is one RCCL call on one bucket.
+"""
+import math
+
+import torch
+
+from . import backend as _be
+
+
+def flatten_parameters(module):
+    """Re-home ``module``'s parameters into one flat buffer; returns (flat_params, flat_grads).
+
+    Parameter objects are preserved (same identity, order, names, state_dict keys);
+    ``load_state_dict`` / in-place updates keep working because they copy into the views.
+    """
+    params = [p for p in module.parameters()]
+    if getattr(module, '_tg_flat', None) is not None:
+        return module._tg_flat
+    n = sum(p.numel() for p in params)
+    dev = params[0].device
+    flat = torch.empty(n, dtype=torch.float32, device=dev)
+    grads = torch.zeros(n, dtype=torch.float32, device=dev)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            k = p.numel()
+            flat[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = flat[off:off + k].view(p.shape)
+            p.grad = grads[off:off + k].view(p.shape)
+            off += k
+    module._tg_flat = (flat, grads)
+    return flat, grads
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics (no weight decay / amsgrad) on one flat buffer.
+
+    The step-dependent scalars (lr / bias_correction1, sqrt(bias_correction2)) are
+    computed on the host in double precision like torch's single-tensor path and
+    handed to the kernel through a 4-float device buffer, so a captured HIP graph
+    of the step stays valid for every step index.
+    """
+
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.module = module
+        self.flat, self.grads = flatten_parameters(module)
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = 0
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
+        self._hyper_host = torch.zeros(4, dtype=torch.float32)
+        if self.flat.is_cuda:
+            self._hyper_host = self._hyper_host.pin_memory()
+
+    def zero_grad(self, set_to_none=False):
+        _be.get().fill(self.grads, 0.0, self.grads.numel())
+
+    def advance(self):
+        """Host half of a step: bump the step index and upload its scalars (not capturable)."""
+        self.step_count += 1
+        b1, b2 = self.betas
+        bc1 = 1 - b1 ** self.step_count
+        bc2 = 1 - b2 ** self.step_count
+        h = self._hyper_host
+        h[0], h[1], h[2], h[3] = self.lr / bc1, math.sqrt(bc2), b1, b2
+        self._hyper.copy_(h, non_blocking=True)
+
+    def apply(self):
+        """Device half of a step: one kernel over the flat buffer (capturable)."""
+        _be.get().adam_step(self.flat, self.grads, self.exp_avg, self.exp_avg_sq, self._hyper,
+                            self.eps, self.flat.numel())
+
+    def step(self):
+        self.advance()
+        self.apply()
+
+    def state_dict(self):
+        return dict(step=self.step_count, lr=self.lr, betas=self.betas, eps=self.eps,
+                    exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone())
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd['step'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+
+
+def ema_update(target_module, source_module, lr):
+    """target += (source - target) * lr over all parameters, one kernel."""
+    t, _ = flatten_parameters(target_module)
+    s, _ = flatten_parameters(source_module)
+    _be.get().ema(t, s, float(lr), t.numel())

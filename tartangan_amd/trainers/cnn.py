@@ -1,0 +1,129 @@
+"""SA-GAN trainer: drop-in for ``tartangan.trainers.cnn.CNNTrainer``
+(reference trainers/cnn.py:28-165) on the HIP engine.
+
+``build_models`` assembles G / target-G / D through the same factory API and
+``train_batch(imgs) -> {g_loss, d_loss, gp}`` performs the reference step
+ -- D phase with BCE-with-logits and the R1 penalty (second
+order), Adam(0, .999), G phase, EMA of G -- with identical op order, RNG
+consumption order, BatchNorm mode and label layout.
+"""
+import functools
+
+import torch
+from torch import nn
+
+from .. import functional as TF
+from ..models.blocks import (
+    DiscriminatorOutput, GeneratorInputMLP, GeneratorOutput, ResidualDiscriminatorBlock,
+    ResidualGeneratorBlock, TiledZGeneratorInput,
+)
+from ..models.layers import BatchNorm2d, LeakyReLU
+from ..models.losses import gradient_penalty
+from ..models.pluggan import GAN_CONFIGS, Discriminator, Generator
+from ..optim import FusedAdam, ema_update
+from .trainer import Trainer
+from .utils import toggle_grad
+
+
+class CNNTrainer(Trainer):
+    discriminator_class = Discriminator
+    d_output_class = DiscriminatorOutput
+
+    # ------------------------------------------------------------------ model assembly
+    def _factories(self):
+        norm = {'id': nn.Identity, 'bn': BatchNorm2d}[self.args.norm]
+        g_input = {'mlp': GeneratorInputMLP, 'tiledz': TiledZGeneratorInput}[self.args.g_base]
+        act = {'relu': functools.partial(LeakyReLU, 0.2)}[self.args.activation]
+        bind = functools.partial
+        return dict(
+            g_input=bind(g_input, activation_factory=act),
+            g_block=bind(ResidualGeneratorBlock, norm_factory=norm, activation_factory=act),
+            d_block=bind(ResidualDiscriminatorBlock, norm_factory=norm, activation_factory=act),
+            g_output=bind(GeneratorOutput, norm_factory=norm, activation_factory=act),
+            d_output=bind(self.d_output_class, norm_factory=norm, activation_factory=act),
+        )
+
+    def build_models(self):
+        config = self.args.config
+        self.gan_config = GAN_CONFIGS[config] if isinstance(config, str) else config
+        self.gan_config = self.gan_config.scale_model(self.args.model_scale)
+        f = self._factories()
+
+        def make_g():
+            return Generator(self.gan_config, input_factory=f['g_input'], block_factory=f['g_block'],
+                             output_factory=f['g_output']).to(self.device)
+        # construction order g, target_g, d consumes the init RNG like the reference (cnn.py:66-83)
+        self.g = make_g()
+        self.target_g = make_g()
+        self.d = self.discriminator_class(self.gan_config, block_factory=f['d_block'],
+                                          output_factory=f['d_output']).to(self.device)
+        self.optimizer_g = FusedAdam(self.g, lr=self.args.lr_g, betas=(0., 0.999))
+        self.optimizer_d = FusedAdam(self.d, lr=self.args.lr_d, betas=(0., 0.999))
+        self.update_target_generator(1.)     # the reference's "copy weights" (see below)
+
+    # ------------------------------------------------------------------ the step
+    def _d_losses(self, real, fake, labels):
+        """-> (p_real, d_loss without penalty); BCE over the concatenated logits (cnn.py:122-131)."""
+        p_real = self.d(real)
+        p_fake = self.d(fake)
+        return p_real, TF.bce_with_logits(torch.cat([p_real, p_fake], dim=0), labels)
+
+    def _g_loss(self, fake, ones):
+        return TF.bce_with_logits(self.d(fake), ones)
+
+    def train_batch(self, imgs):
+        imgs = imgs.to(self.device)
+        bs = len(imgs)
+        self.g.train()
+        self.d.train()
+        # ---- discriminator phase
+        toggle_grad(self.g, False)
+        toggle_grad(self.d, True)
+        self.optimizer_d.zero_grad()
+        fake = self.sample_g(bs)
+        labels = torch.zeros(2 * bs, 1, device=self.device)
+        labels[:bs] = 1
+        real = imgs.detach()
+        if self.args.grad_penalty:
+            real = real.clone().requires_grad_()
+        p_real, d_loss = self._d_losses(real, fake.detach(), labels)
+        d_grad_penalty = None
+        if self.args.grad_penalty:
+            d_grad_penalty = TF.scale(gradient_penalty(p_real, real), self.args.grad_penalty)
+            d_loss = TF.add(d_loss, d_grad_penalty)
+        d_loss.backward()
+        self._reduce_gradients(self.optimizer_d)
+        self.optimizer_d.step()
+        # ---- generator phase
+        toggle_grad(self.g, True)
+        toggle_grad(self.d, False)
+        self.optimizer_g.zero_grad()
+        fake = self.sample_g(bs)
+        g_loss = self._g_loss(fake, torch.ones(bs, 1, device=self.device))
+        g_loss.backward()
+        self._reduce_gradients(self.optimizer_g)
+        self.optimizer_g.step()
+        self.update_target_generator()
+        self.steps += 1
+        vals = [g_loss.detach(), d_loss.detach()]
+        if d_grad_penalty is not None:
+            vals.append(d_grad_penalty.detach())
+        vals = torch.stack(vals).tolist()            # one device->host read for all three
+        return dict(g_loss=vals[0], d_loss=vals[1], gp=vals[2] if d_grad_penalty is not None else 0.)
+
+    def _reduce_gradients(self, optimizer):
+        """Data-parallel hook: average the flat gradient bucket over ranks (no-op on 1 GPU)."""
+        dp = getattr(self, 'data_parallel', None)
+        if dp is not None:
+            dp.all_reduce_mean(optimizer.grads)
+
+    @torch.no_grad()
+    def update_target_generator(self, lr=None):
+        """target += (g - target) * lr_target_g.  Like the reference (cnn.py:158-165) the
+        ``lr`` argument is accepted and ignored: build_models' update_target_generator(1.)
+        therefore moves target_g only 1e-3 of the way towards g, it does not copy."""
+        ema_update(self.target_g, self.g, self.args.lr_target_g)
+
+
+def main():
+    raise SystemExit('The CLI/epoch loop stays with tartangan; see INTEGRATION.md for the drop-in.')

@@ -1,0 +1,299 @@
+"""Reference semantics of every entry point in include/tartangan_amd.h, written
+with plain PyTorch ops.  TEST INFRASTRUCTURE ONLY (lives under tests/).
+
+Two uses:
+  * ``-m "not gpu"``: installed through ``backend._set_backend_for_testing`` so the
+    host logic (autograd composition, double backward, trainers, optimiser,
+    data-parallel glue) can be checked on CPU against the oracle and the golden
+    fixtures.  The product never falls back to this.
+  * ``-m gpu``: per-kernel expected values for the HIP kernels (same call, CPU
+    copies of the same inputs).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _v(t, *shape):
+    return t.view(*shape)
+
+
+class Emulator:
+    name = 'emulator'
+
+    # ---------------------------------------------------------------- conv
+    def conv2d_fwd(self, x, w, bias, y, B, Cin, Cout, H, W, ks):
+        y.copy_(F.conv2d(_v(x, B, Cin, H, W), _v(w, Cout, Cin, ks, ks), bias, padding=ks // 2))
+        return 0
+
+    def conv2d_dgrad(self, gy, w, gx, B, Cin, Cout, H, W, ks):
+        gx.copy_(F.conv_transpose2d(_v(gy, B, Cout, H, W), _v(w, Cout, Cin, ks, ks), padding=ks // 2))
+        return 0
+
+    def conv2d_wgrad_workspace(self, B, Cin, Cout, H, W, ks):
+        return 16
+
+    def conv2d_wgrad(self, x, gy, gw, ws, ws_bytes, B, Cin, Cout, H, W, ks):
+        gw.copy_(torch.nn.grad.conv2d_weight(_v(x, B, Cin, H, W), (Cout, Cin, ks, ks),
+                                             _v(gy, B, Cout, H, W), padding=ks // 2))
+        return 0
+
+    def channel_sum(self, x, out, B, C, HW):
+        out.copy_(_v(x, B, C, HW).sum((0, 2)))
+        return 0
+
+    def channel_bcast(self, v, out, B, C, HW):
+        _v(out, B, C, HW).copy_(_v(v, 1, C, 1).expand(B, C, HW))
+        return 0
+
+    # ---------------------------------------------------------------- gemm
+    def gemm(self, A, Bm, C, bias, M, N, K, lda, ldb, ldc, ta, tb, batch, sA, sB, sC):
+        a = A.reshape(batch, -1, lda)
+        b = Bm.reshape(batch, -1, ldb)
+        a = a.transpose(1, 2) if ta else a
+        b = b.transpose(1, 2) if tb else b
+        r = torch.bmm(a, b)
+        if bias is not None:
+            r = r + bias.view(1, 1, N)
+        C.view(batch, M, N).copy_(r)
+        return 0
+
+    # ---------------------------------------------------------------- batch norm
+    def bn_workspace(self, B, C, HW):
+        return 16
+
+    def bn_train_stats(self, x, mean, invstd, rm, rv, momentum, eps, ws, B, C, HW):
+        xv = _v(x, B, C, HW)
+        n = B * HW
+        m = xv.mean((0, 2))
+        var = xv.var((0, 2), unbiased=False)
+        mean.copy_(m)
+        invstd.copy_(1 / torch.sqrt(var + eps))
+        if rm is not None:
+            rm.mul_(1 - momentum).add_(momentum * m)
+            rv.mul_(1 - momentum).add_(momentum * var * (n / max(n - 1, 1)))
+        return 0
+
+    def bn_eval_stats(self, rm, rv, mean, invstd, eps, C):
+        mean.copy_(rm)
+        invstd.copy_(1 / torch.sqrt(rv + eps))
+        return 0
+
+    @staticmethod
+    def _bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW):
+        xv = _v(x, B, C, HW)
+        xhat = (xv - mean.view(1, C, 1)) * invstd.view(1, C, 1)
+        y = xhat * gamma.view(1, C, 1) + beta.view(1, C, 1)
+        s = torch.where(y >= 0, torch.ones_like(y), torch.full_like(y, slope))
+        return xhat, y, s
+
+    def bn_act_fwd(self, x, mean, invstd, gamma, beta, slope, z, B, C, HW):
+        xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
+        _v(z, B, C, HW).copy_(y * s)
+        return 0
+
+    def bn_act_bwd(self, gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, ws, B, C, HW):
+        xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
+        gyh = _v(gz, B, C, HW) * s
+        n = B * HW
+        sb = gyh.sum((0, 2))
+        sg = (gyh * xhat).sum((0, 2))
+        gg.copy_(sg)
+        gb.copy_(sb)
+        if gx is not None:
+            k = (gamma * invstd).view(1, C, 1)
+            if training:
+                r = k * (gyh - sb.view(1, C, 1) / n - xhat * sg.view(1, C, 1) / n)
+            else:
+                r = k * gyh
+            _v(gx, B, C, HW).copy_(r)
+        return 0
+
+    def bn_act_dbwd(self, v, vg, vb, gz, x, mean, invstd, gamma, beta, slope, a_gz, a_x, a_gamma, ws, B, C, HW):
+        xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
+        n = B * HW
+        c = lambda t: t.view(1, C, 1)
+        gyh = _v(gz, B, C, HW) * s
+        vv = _v(v, B, C, HW)
+        vg = torch.zeros_like(gamma) if vg is None else vg
+        vb = torch.zeros_like(gamma) if vb is None else vb
+        S1, S2 = vv.sum((0, 2)), (vv * xhat).sum((0, 2))
+        S3, S4 = gyh.sum((0, 2)), (gyh * xhat).sum((0, 2))
+        S5 = (vv * gyh).sum((0, 2))
+        r = invstd
+        # adjoint of gyh: gamma r P(v) + vgamma xhat + vbeta
+        Pv = vv - c(S1) / n - xhat * c(S2) / n
+        a_gyh = c(gamma * r) * Pv + c(vg) * xhat + c(vb)
+        _v(a_gz, B, C, HW).copy_(a_gyh * s)
+        # adjoint of gamma: r * sum v P(gyh)
+        A = S5 - S1 * S3 / n - S2 * S4 / n
+        a_gamma.copy_(r * A)
+        # adjoint of x
+        cg, cv = S4 / n, S2 / n
+        q = -c(gamma * r) * (c(cg) * vv + c(cv) * gyh) + c(vg) * gyh
+        qm = q.sum((0, 2)) / n
+        qx = (q * xhat).sum((0, 2)) / n
+        Pq = q - c(qm) - xhat * c(qx)
+        _v(a_x, B, C, HW).copy_(c(r) * Pq - c(gamma * A * r * r / n) * xhat)
+        return 0
+
+    # ---------------------------------------------------------------- resampling
+    def up2x(self, x, y, alpha, BC, H, W):
+        _v(y, BC, 2 * H, 2 * W).copy_(alpha * _v(x, BC, H, W).repeat_interleave(2, 1).repeat_interleave(2, 2))
+        return 0
+
+    def pool2(self, x, y, alpha, BC, H, W):
+        _v(y, BC, H // 2, W // 2).copy_(alpha * 4 * F.avg_pool2d(_v(x, 1, BC, H, W), 2)[0])
+        return 0
+
+    def bilinear_half_fwd(self, x, y, BC, H, W):
+        _v(y, BC, H // 2, W // 2).copy_(F.interpolate(_v(x, 1, BC, H, W), scale_factor=0.5, mode='bilinear',
+                                                      align_corners=True)[0])
+        return 0
+
+    def bilinear_half_bwd(self, gy, gx, BC, H, W):
+        with torch.enable_grad():
+            xin = torch.zeros(1, BC, H, W, requires_grad=True)
+            out = F.interpolate(xin, scale_factor=0.5, mode='bilinear', align_corners=True)
+            g, = torch.autograd.grad(out, xin, _v(gy, 1, BC, H // 2, W // 2).detach())
+        _v(gx, BC, H, W).copy_(g[0])
+        return 0
+
+    def maxpool2_fwd(self, x, y, idx, BC, H, W):
+        xv = _v(x, BC, H // 2, 2, W // 2, 2).permute(0, 1, 3, 2, 4).reshape(BC, H // 2, W // 2, 4)
+        # first maximum in window order (NaN-free inputs)
+        m = xv.max(-1, keepdim=True).values
+        first = (xv == m).to(torch.uint8).argmax(-1)
+        _v(y, BC, H // 2, W // 2).copy_(m.squeeze(-1))
+        _v(idx, BC, H // 2, W // 2).copy_(first.to(torch.uint8))
+        return 0
+
+    def maxpool2_bwd(self, gy, idx, gx, BC, H, W):
+        oh, ow = H // 2, W // 2
+        onehot = F.one_hot(_v(idx, BC, oh, ow).long(), 4).to(gy.dtype) * _v(gy, BC, oh, ow, 1)
+        _v(gx, BC, H, W).copy_(onehot.view(BC, oh, ow, 2, 2).permute(0, 1, 3, 2, 4).reshape(BC, H, W))
+        return 0
+
+    def maxpool2_gather(self, x, idx, y, BC, H, W):
+        oh, ow = H // 2, W // 2
+        xv = _v(x, BC, oh, 2, ow, 2).permute(0, 1, 3, 2, 4).reshape(BC, oh, ow, 4)
+        _v(y, BC, oh, ow).copy_(xv.gather(-1, _v(idx, BC, oh, ow, 1).long()).squeeze(-1))
+        return 0
+
+    # ---------------------------------------------------------------- row ops
+    def row_sum(self, x, out, alpha, rows, cols):
+        out.view(rows).copy_(alpha * _v(x, rows, cols).sum(1))
+        return 0
+
+    def row_bcast(self, v, out, alpha, rows, cols):
+        _v(out, rows, cols).copy_(alpha * v.reshape(rows, 1).expand(rows, cols))
+        return 0
+
+    def repeat_rows(self, x, out, alpha, rows, cols, reps):
+        _v(out, reps, rows, cols).copy_(alpha * _v(x, 1, rows, cols).expand(reps, rows, cols))
+        return 0
+
+    def sum_reps(self, x, out, alpha, rows, cols, reps):
+        _v(out, rows, cols).copy_(alpha * _v(x, reps, rows, cols).sum(0))
+        return 0
+
+    # ---------------------------------------------------------------- elementwise
+    def add(self, a, b, out, n):
+        out.copy_(a + b)
+        return 0
+
+    def mul(self, a, b, out, n):
+        out.copy_(a * b)
+        return 0
+
+    def scale(self, x, alpha, out, n):
+        out.copy_(x * alpha)
+        return 0
+
+    def scale_dev(self, s, alpha, x, out, n):
+        out.copy_((alpha * s.reshape(())) * x)
+        return 0
+
+    def scale_add_dev(self, s, a, b, out, n):
+        out.copy_(s.reshape(()) * a + b)
+        return 0
+
+    def reduce_workspace(self, n):
+        return 16
+
+    def dot(self, a, b, alpha, out, ws, n):
+        out.copy_(alpha * (a.double() * b.double()).sum().float())
+        return 0
+
+    def lrelu_bwd(self, g, x, slope, out, n):
+        out.copy_(torch.where(x >= 0, g, g * slope))
+        return 0
+
+    def tanh_fwd(self, x, y, n):
+        y.copy_(torch.tanh(x))
+        return 0
+
+    def tanh_bwd(self, g, y, out, n):
+        out.copy_(g * (1 - y * y))
+        return 0
+
+    def fill(self, x, value, n):
+        x.fill_(value)
+        return 0
+
+    # ---------------------------------------------------------------- softmax
+    def softmax_fwd(self, s, y, rows, cols):
+        _v(y, rows, cols).copy_(F.softmax(_v(s, rows, cols), -1))
+        return 0
+
+    def softmax_bwd(self, gy, y, gs, rows, cols):
+        g, yy = _v(gy, rows, cols), _v(y, rows, cols)
+        _v(gs, rows, cols).copy_(yy * (g - (g * yy).sum(-1, keepdim=True)))
+        return 0
+
+    def softmax_dbwd(self, v, gy, y, out, rows, cols):
+        vv, g, yy = _v(v, rows, cols), _v(gy, rows, cols), _v(y, rows, cols)
+        d = (g * yy).sum(-1, keepdim=True)
+        e = (vv * yy).sum(-1, keepdim=True)
+        _v(out, rows, cols).copy_(vv * g - vv * d - g * e)
+        return 0
+
+    # ---------------------------------------------------------------- iqn / losses
+    def iqn_cos_embed(self, taus, rng, out, n, dims):
+        out.copy_(torch.cos(taus.view(n, 1).repeat(1, dims) * math.pi * rng))
+        return 0
+
+    def iqn_loss(self, preds, target, taus, k, loss, dpreds, ws, Q, B):
+        p = preds.view(Q, B)
+        err = target.view(1, B) - p
+        a = err.abs()
+        hub = torch.where(a <= k, 0.5 * err * err, k * (a - 0.5 * k))
+        dhub = torch.where(a <= k, err, k * torch.sign(err))        # d huber / d err
+        wgt = (taus.view(Q, B) - (err < 0).float()).abs()
+        loss.copy_((wgt * hub).sum(0).mean())
+        dpreds.view(Q, B).copy_(-wgt * dhub / B)
+        return 0
+
+    def bce_logits(self, logits, targets, loss, dlogits, ws, n):
+        x, t = logits.view(-1), targets.view(-1)
+        loss.copy_(F.binary_cross_entropy_with_logits(x, t))
+        dlogits.view(-1).copy_((torch.sigmoid(x) - t) / n)
+        return 0
+
+    def sumsq(self, x, alpha, out, ws, n):
+        out.copy_(alpha * x.pow(2).sum())
+        return 0
+
+    # ---------------------------------------------------------------- optimiser
+    def adam_step(self, p, g, m, v, hyper, eps, n):
+        step_size, bc2_sqrt, b1, b2 = [float(h) for h in hyper]
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / bc2_sqrt).add_(eps)
+        p.addcdiv_(m, denom, value=-step_size)
+        return 0
+
+    def ema(self, t, p, lr, n):
+        t.add_((p - t) * lr)
+        return 0
