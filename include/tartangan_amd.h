@@ -50,8 +50,8 @@ int tg_conv2d_dgrad(const float* gy, const float* w, float* gx,
 size_t tg_conv2d_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ks);
 int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* workspace, size_t workspace_bytes,
                     int B, int Cin, int Cout, int H, int W, int ks, void* stream);
-/* out[c] = sum_{b,p} x[b][c][p]   (conv bias grad; torch.sum(feats,[2,3]) with B*C rows) */
-int tg_channel_sum(const float* x, float* out, int B, int C, int HW, void* stream);
+/* out[c] = sum_{b,p} x[b][c][p]   (conv / linear bias grad); workspace: tg_bn_workspace(B,C,HW) bytes */
+int tg_channel_sum(const float* x, float* out, float* workspace, int B, int C, int HW, void* stream);
 /* out[b][c][p] = v[c] (transpose of tg_channel_sum) */
 int tg_channel_bcast(const float* v, float* out, int B, int C, int HW, void* stream);
 
@@ -66,7 +66,7 @@ int tg_gemm(const float* A, const float* Bm, float* C, const float* bias_n /*nul
 /* ---------------------------------------------------------------- BatchNorm2d (+LeakyReLU)
  * nn.BatchNorm2d train mode followed by nn.LeakyReLU(0.2): generator.py:38-44,
  * discriminator.py:60-66,133-136,153-156.  slope = 1 gives plain BatchNorm.
- * Workspace: tg_bn_workspace(C) bytes.                                         */
+ * Workspace: tg_bn_workspace(B,C,HW) bytes.                                       */
 size_t tg_bn_workspace(int B, int C, int HW);
 /* batch mean / 1/sqrt(biased var + eps); optional running-stat update
  * (running_var uses the unbiased variance, momentum as nn.BatchNorm2d)         */
@@ -169,8 +169,8 @@ int tg_sumsq(const float* x, float alpha, float* out, float* workspace, int64_t 
 
 /* ---------------------------------------------------------------- optimiser / EMA
  * torch.optim.Adam (trainers/cnn.py:84-85), single flat tensor.
- * hyper (device, 4 floats): [lr/bias_correction1, sqrt(bias_correction2), beta1, beta2]
- * so the captured graph is step-independent:
+ * hyper (device, 6 floats): [lr/bias_correction1, sqrt(bias_correction2), beta1, beta2,
+ * 1-beta1, 1-beta2] (host doubles rounded to fp32) so the captured graph is step-independent:
  *   m = lerp(m, g, 1-beta1); v = beta2*v + (1-beta2)*g*g;
  *   p -= hyper[0] * m / (sqrt(v)/hyper[1] + eps)                                        */
 int tg_adam_step(float* p, const float* g, float* m, float* v, const float* hyper, float eps,

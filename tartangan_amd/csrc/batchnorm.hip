@@ -1,0 +1,340 @@
+// BatchNorm2d (train / eval) fused with LeakyReLU: forward, backward and the second
+// backward needed by the R1 penalty.  HBM-bound; per-channel sums are two-stage and
+// deterministic (fp32 per-thread partials over <= ~64 elements, fp64 across threads/blocks).
+//
+// Notation per channel (n = B*HW): xhat = (x-mean)*invstd, y = gamma*xhat+beta,
+// s = lrelu'(y) in {1, slope}, gyh = gz*s.
+//   fwd : z = y*s
+//   bwd : gbeta = S(gyh); ggamma = S(gyh*xhat); gx = gamma*invstd*(gyh - gbeta/n - xhat*ggamma/n)
+//   dbwd: see tg_bn_act_dbwd below (derivation in DESIGN.md "BatchNorm second backward").
+#include "planes.h"
+
+namespace {
+
+using planes::BLOCK;
+
+// workspace layout: [C*S*5] doubles of partial sums, then [C*COEF] floats of per-channel coefficients
+constexpr int COEF = 8;
+constexpr int MAXK = 5;
+
+__device__ __forceinline__ float bn_y(float x, float a, float b) { return fmaf(x, a, b); }   // a = gamma*invstd, b = beta - mean*a
+
+struct Parts {
+  double* partial;
+  float* coef;
+};
+static inline Parts split_ws(float* ws, int B, int C, int HW) {
+  const int S = planes::splits(B, C, HW);
+  Parts p;
+  p.partial = reinterpret_cast<double*>(ws);
+  p.coef = reinterpret_cast<float*>(p.partial + (size_t)C * S * MAXK);
+  return p;
+}
+
+// ------------------------------------------------------------------ statistics
+struct RedStats {
+  static constexpr int K = 2;
+  const float* x;
+  int C, HW;
+  float pivot;
+  __device__ void init(int c) { pivot = x[(int64_t)c * HW]; }   // first element of the channel: shift against cancellation
+  __device__ void acc4(int64_t off, float* a) {
+    const float4 v = *reinterpret_cast<const float4*>(x + off);
+    const float d0 = v.x - pivot, d1 = v.y - pivot, d2 = v.z - pivot, d3 = v.w - pivot;
+    a[0] += (d0 + d1) + (d2 + d3);
+    a[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  __device__ void acc1(int64_t off, float* a) {
+    const float d = x[off] - pivot;
+    a[0] += d;
+    a[1] += d * d;
+  }
+};
+
+__global__ void stats_stage2(const double* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
+                             float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv, float momentum,
+                             float eps, int B, int C, int HW, int S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = (double)B * HW;
+  const double pivot = (double)x[(int64_t)c * HW];
+  const double s1 = planes::gather(partial, c, S, 2, 0) / n;
+  const double s2 = planes::gather(partial, c, S, 2, 1) / n;
+  const double m = pivot + s1;
+  double var = s2 - s1 * s1;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rm != nullptr) {
+    const double unbiased = n > 1.0 ? var * (n / (n - 1.0)) : var;
+    rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * m);
+    rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
+  }
+}
+
+__global__ void eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ mean,
+                                  float* __restrict__ invstd, float eps, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  invstd[c] = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+}
+
+// ------------------------------------------------------------------ forward apply
+struct FwdBody {
+  const float* x; float* z;
+  const float *mean, *invstd, *gamma, *beta;
+  float slope;
+  __device__ void coeffs(int c, float& a, float& b) const {
+    a = gamma[c] * invstd[c];
+    b = beta[c] - mean[c] * a;
+  }
+  __device__ void vec4(int c, int64_t off) const {
+    float a, b; coeffs(c, a, b);
+    const float4 v = *reinterpret_cast<const float4*>(x + off);
+    float4 r;
+    float y;
+    y = bn_y(v.x, a, b); r.x = y >= 0.f ? y : y * slope;
+    y = bn_y(v.y, a, b); r.y = y >= 0.f ? y : y * slope;
+    y = bn_y(v.z, a, b); r.z = y >= 0.f ? y : y * slope;
+    y = bn_y(v.w, a, b); r.w = y >= 0.f ? y : y * slope;
+    *reinterpret_cast<float4*>(z + off) = r;
+  }
+  __device__ void one(int c, int64_t off) const {
+    float a, b; coeffs(c, a, b);
+    const float y = bn_y(x[off], a, b);
+    z[off] = y >= 0.f ? y : y * slope;
+  }
+};
+
+// ------------------------------------------------------------------ first backward
+struct RedBwd {
+  static constexpr int K = 2;
+  const float *gz, *x, *mean, *invstd, *gamma, *beta;
+  float slope;
+  float a, b, mu, r;
+  __device__ void init(int c) {
+    r = invstd[c]; mu = mean[c];
+    a = gamma[c] * r;
+    b = beta[c] - mu * a;
+  }
+  __device__ void elem(float g, float xv, float* acc) {
+    const float y = bn_y(xv, a, b);
+    const float gyh = y >= 0.f ? g : g * slope;
+    acc[0] += gyh;
+    acc[1] += gyh * ((xv - mu) * r);
+  }
+  __device__ void acc4(int64_t off, float* acc) {
+    const float4 g = *reinterpret_cast<const float4*>(gz + off);
+    const float4 v = *reinterpret_cast<const float4*>(x + off);
+    elem(g.x, v.x, acc); elem(g.y, v.y, acc); elem(g.z, v.z, acc); elem(g.w, v.w, acc);
+  }
+  __device__ void acc1(int64_t off, float* acc) { elem(gz[off], x[off], acc); }
+};
+
+__global__ void bwd_stage2(const double* __restrict__ partial, float* __restrict__ ggamma, float* __restrict__ gbeta,
+                           float* __restrict__ coef, int B, int C, int HW, int S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = (double)B * HW;
+  const double sb = planes::gather(partial, c, S, 2, 0);
+  const double sg = planes::gather(partial, c, S, 2, 1);
+  gbeta[c] = (float)sb;
+  ggamma[c] = (float)sg;
+  coef[c * COEF + 0] = (float)(sb / n);
+  coef[c * COEF + 1] = (float)(sg / n);
+}
+
+struct BwdBody {
+  const float *gz, *x; float* gx;
+  const float *mean, *invstd, *gamma, *beta, *coef;
+  float slope; int training;
+  __device__ float elem(float g, float xv, float a, float b, float mu, float r, float k1, float k2) const {
+    const float y = bn_y(xv, a, b);
+    const float gyh = y >= 0.f ? g : g * slope;
+    return training ? a * (gyh - k1 - ((xv - mu) * r) * k2) : a * gyh;
+  }
+  __device__ void vec4(int c, int64_t off) const {
+    const float r = invstd[c], mu = mean[c], a = gamma[c] * r, b = beta[c] - mu * a;
+    const float k1 = coef[c * COEF + 0], k2 = coef[c * COEF + 1];
+    const float4 g = *reinterpret_cast<const float4*>(gz + off);
+    const float4 v = *reinterpret_cast<const float4*>(x + off);
+    float4 o;
+    o.x = elem(g.x, v.x, a, b, mu, r, k1, k2); o.y = elem(g.y, v.y, a, b, mu, r, k1, k2);
+    o.z = elem(g.z, v.z, a, b, mu, r, k1, k2); o.w = elem(g.w, v.w, a, b, mu, r, k1, k2);
+    *reinterpret_cast<float4*>(gx + off) = o;
+  }
+  __device__ void one(int c, int64_t off) const {
+    const float r = invstd[c], mu = mean[c], a = gamma[c] * r, b = beta[c] - mu * a;
+    gx[off] = elem(gz[off], x[off], a, b, mu, r, coef[c * COEF + 0], coef[c * COEF + 1]);
+  }
+};
+
+// ------------------------------------------------------------------ second backward
+struct RedDbwd {
+  static constexpr int K = 5;   // S1 = S(v), S2 = S(v xhat), S3 = S(gyh), S4 = S(gyh xhat), S5 = S(v gyh)
+  const float *v, *gz, *x, *mean, *invstd, *gamma, *beta;
+  float slope;
+  float a, b, mu, r;
+  __device__ void init(int c) {
+    r = invstd[c]; mu = mean[c];
+    a = gamma[c] * r;
+    b = beta[c] - mu * a;
+  }
+  __device__ void elem(float vv, float g, float xv, float* acc) {
+    const float y = bn_y(xv, a, b);
+    const float gyh = y >= 0.f ? g : g * slope;
+    const float xh = (xv - mu) * r;
+    acc[0] += vv; acc[1] += vv * xh; acc[2] += gyh; acc[3] += gyh * xh; acc[4] += vv * gyh;
+  }
+  __device__ void acc4(int64_t off, float* acc) {
+    const float4 w = *reinterpret_cast<const float4*>(v + off);
+    const float4 g = *reinterpret_cast<const float4*>(gz + off);
+    const float4 q = *reinterpret_cast<const float4*>(x + off);
+    elem(w.x, g.x, q.x, acc); elem(w.y, g.y, q.y, acc); elem(w.z, g.z, q.z, acc); elem(w.w, g.w, q.w, acc);
+  }
+  __device__ void acc1(int64_t off, float* acc) { elem(v[off], gz[off], x[off], acc); }
+};
+
+// coef: 0 S1/n  1 S2/n  2 cg  3 cv  4 qm  5 qx  6 gamma*A*r^2/n
+__global__ void dbwd_stage2(const double* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ invstd,
+                            const float* __restrict__ vgamma, float* __restrict__ adj_gamma, float* __restrict__ coef,
+                            int B, int C, int HW, int S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = (double)B * HW;
+  const double S1 = planes::gather(partial, c, S, 5, 0), S2 = planes::gather(partial, c, S, 5, 1);
+  const double S3 = planes::gather(partial, c, S, 5, 2), S4 = planes::gather(partial, c, S, 5, 3);
+  const double S5 = planes::gather(partial, c, S, 5, 4);
+  const double r = (double)invstd[c], g = (double)gamma[c];
+  const double vg = vgamma ? (double)vgamma[c] : 0.0;
+  const double A = S5 - S1 * S3 / n - S2 * S4 / n;
+  const double cg = S4 / n, cv = S2 / n;
+  const double qm = -g * r * (cg * S1 / n + cv * S3 / n) + vg * S3 / n;
+  const double qx = -g * r * (cg * S2 / n + cv * S4 / n) + vg * S4 / n;
+  adj_gamma[c] = (float)(r * A);
+  float* k = coef + c * COEF;
+  k[0] = (float)(S1 / n); k[1] = (float)(S2 / n); k[2] = (float)cg; k[3] = (float)cv;
+  k[4] = (float)qm; k[5] = (float)qx; k[6] = (float)(g * A * r * r / n);
+}
+
+struct DbwdBody {
+  const float *v, *gz, *x; float *adj_gz, *adj_x;
+  const float *mean, *invstd, *gamma, *beta, *vgamma, *vbeta, *coef;
+  float slope;
+  struct Ch { float r, mu, a, b, gr, vg, vb, k0, k1, cg, cv, qm, qx, k6; };
+  __device__ Ch load(int c) const {
+    Ch h;
+    h.r = invstd[c]; h.mu = mean[c]; h.a = gamma[c] * h.r; h.b = beta[c] - h.mu * h.a; h.gr = h.a;
+    h.vg = vgamma ? vgamma[c] : 0.f; h.vb = vbeta ? vbeta[c] : 0.f;
+    const float* k = coef + c * COEF;
+    h.k0 = k[0]; h.k1 = k[1]; h.cg = k[2]; h.cv = k[3]; h.qm = k[4]; h.qx = k[5]; h.k6 = k[6];
+    return h;
+  }
+  __device__ void elem(const Ch& h, float vv, float g, float xv, float& o_gz, float& o_x) const {
+    const float y = bn_y(xv, h.a, h.b);
+    const float s = y >= 0.f ? 1.f : slope;
+    const float gyh = g * s;
+    const float xh = (xv - h.mu) * h.r;
+    const float pv = vv - h.k0 - xh * h.k1;
+    o_gz = (h.gr * pv + h.vg * xh + h.vb) * s;
+    const float q = -h.gr * (h.cg * vv + h.cv * gyh) + h.vg * gyh;
+    o_x = h.r * (q - h.qm - xh * h.qx) - h.k6 * xh;
+  }
+  __device__ void vec4(int c, int64_t off) const {
+    const Ch h = load(c);
+    const float4 w = *reinterpret_cast<const float4*>(v + off);
+    const float4 g = *reinterpret_cast<const float4*>(gz + off);
+    const float4 q = *reinterpret_cast<const float4*>(x + off);
+    float4 og, ox;
+    elem(h, w.x, g.x, q.x, og.x, ox.x); elem(h, w.y, g.y, q.y, og.y, ox.y);
+    elem(h, w.z, g.z, q.z, og.z, ox.z); elem(h, w.w, g.w, q.w, og.w, ox.w);
+    *reinterpret_cast<float4*>(adj_gz + off) = og;
+    *reinterpret_cast<float4*>(adj_x + off) = ox;
+  }
+  __device__ void one(int c, int64_t off) const {
+    const Ch h = load(c);
+    elem(h, v[off], gz[off], x[off], adj_gz[off], adj_x[off]);
+  }
+};
+
+static inline int chan_grid(int C) { return (C + 63) / 64; }
+
+}  // namespace
+
+extern "C" {
+
+size_t tg_bn_workspace(int B, int C, int HW) {
+  if (B <= 0 || C <= 0 || HW <= 0) return 0;
+  const int S = planes::splits(B, C, HW);
+  return (size_t)C * S * MAXK * sizeof(double) + (size_t)C * COEF * sizeof(float);
+}
+
+int tg_bn_train_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var, float momentum,
+                      float eps, float* workspace, int B, int C, int HW, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  if ((running_mean == nullptr) != (running_var == nullptr)) return TG_EINVAL;
+  hipStream_t st = tg_stream(stream);
+  Parts p = split_ws(workspace, B, C, HW);
+  RedStats red{x, C, HW, 0.f};
+  planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x));
+  stats_stage2<<<chan_grid(C), 64, 0, st>>>(p.partial, x, mean, invstd, running_mean, running_var, momentum, eps, B, C, HW,
+                                            planes::splits(B, C, HW));
+  return tg_launch_status();
+}
+
+int tg_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, float eps, int C,
+                     void* stream) {
+  TG_CHECK_PTR(running_mean); TG_CHECK_PTR(running_var); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd);
+  TG_CHECK_POS(C);
+  eval_stats_kernel<<<chan_grid(C), 64, 0, tg_stream(stream)>>>(running_mean, running_var, mean, invstd, eps, C);
+  return tg_launch_status();
+}
+
+int tg_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                  float* z, int B, int C, int HW, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta); TG_CHECK_PTR(z);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  FwdBody body{x, z, mean, invstd, gamma, beta, slope};
+  planes::launch_map(body, B, C, HW, tg_stream(stream), tg_aligned16(x) && tg_aligned16(z));
+  return tg_launch_status();
+}
+
+int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, float slope, int training, float* gx, float* ggamma, float* gbeta, float* workspace,
+                  int B, int C, int HW, void* stream) {
+  TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta);
+  TG_CHECK_PTR(ggamma); TG_CHECK_PTR(gbeta); TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  hipStream_t st = tg_stream(stream);
+  Parts p = split_ws(workspace, B, C, HW);
+  RedBwd red{gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
+  planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz));
+  bwd_stage2<<<chan_grid(C), 64, 0, st>>>(p.partial, ggamma, gbeta, p.coef, B, C, HW, planes::splits(B, C, HW));
+  if (gx != nullptr) {
+    BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, training};
+    planes::launch_map(body, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx));
+  }
+  return tg_launch_status();
+}
+
+int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, const float* gz, const float* x,
+                   const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                   float* adj_gz, float* adj_x, float* adj_gamma, float* workspace, int B, int C, int HW, void* stream) {
+  TG_CHECK_PTR(v); TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma);
+  TG_CHECK_PTR(beta); TG_CHECK_PTR(adj_gz); TG_CHECK_PTR(adj_x); TG_CHECK_PTR(adj_gamma); TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  hipStream_t st = tg_stream(stream);
+  Parts p = split_ws(workspace, B, C, HW);
+  RedDbwd red{v, gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
+  const bool al = tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(v) && tg_aligned16(adj_gz) && tg_aligned16(adj_x);
+  planes::launch_reduce(red, p.partial, B, C, HW, st, al);
+  dbwd_stage2<<<chan_grid(C), 64, 0, st>>>(p.partial, gamma, invstd, vgamma, adj_gamma, p.coef, B, C, HW,
+                                           planes::splits(B, C, HW));
+  DbwdBody body{v, gz, x, adj_gz, adj_x, mean, invstd, gamma, beta, vgamma, vbeta, p.coef, slope};
+  planes::launch_map(body, B, C, HW, st, al);
+  return tg_launch_status();
+}
+
+}  // extern "C"

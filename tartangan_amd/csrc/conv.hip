@@ -1,0 +1,479 @@
+// fp32 convolution (3x3 pad 1 / 1x1, stride 1, NCHW) as LDS-staged implicit GEMM on the
+// gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact fp32,
+// bit-identical to an fmaf chain, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).
+//
+//   forward / dgrad : M = Cout tile, N = 256 output pixels, K = (ci, tap).  The input patch
+//                     (with halo) and the filter slice are staged once per Cin chunk; A/B
+//                     fragments are single ds_read_b32 with compile-time offsets.  dgrad is the
+//                     same kernel reading the filter transposed + spatially flipped.
+//   wgrad           : M = Cout tile, N = (ci, tap) columns, K = pixels; each workgroup keeps its
+//                     gw slice in MFMA accumulators while it walks its share of pixel tiles,
+//                     then writes ONE partial; a second kernel sums the partials in a fixed
+//                     order (deterministic, no float atomics).
+//
+// Pixel tiles (256 output pixels per workgroup, 64 per wave):
+//   G4  : 16 whole 4x4 images      G8 : 4 whole 8x8 images     G16 : one 16x16 image
+//   GX  : 8 rows x 32 cols inside one image (any H, W; edges guarded)
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CT_THREADS = 256;
+
+template <int TH_, int TW_, int NI_>
+struct Geo {
+  static constexpr int TH = TH_, TW = TW_, NI = NI_;
+  static_assert(TH_ * TW_ * NI_ == 256, "a pixel tile is 256 pixels");
+};
+using G4 = Geo<4, 4, 16>;
+using G8 = Geo<8, 8, 4>;
+using G16 = Geo<16, 16, 1>;
+using GX = Geo<8, 32, 1>;
+
+template <class G, int KS>
+struct Patch {
+  static constexpr int PAD = KS / 2;
+  static constexpr int PH = G::TH + KS - 1, PW = G::TW + KS - 1;
+  static constexpr int PWS = PW;                       // row stride
+  static constexpr int IMG = PH * PWS;                 // one image's patch
+  static constexpr int RAW = G::NI * IMG;
+  static constexpr int CIS = ((RAW + 31) / 32) * 32 + 16;   // per-channel stride; %32 == 16 keeps the two
+                                                            // k-halves of a 32-lane LDS group on disjoint banks
+};
+
+struct Shape {
+  int B, Cin, Cout, H, W;
+};
+
+struct TileCoord {
+  int b0, h0, w0;
+};
+
+template <class G>
+__device__ __forceinline__ TileCoord decode_tile(int t, int H, int W) {
+  const int tw_tiles = (W + G::TW - 1) / G::TW, th_tiles = (H + G::TH - 1) / G::TH;
+  const int per = tw_tiles * th_tiles;
+  const int grp = t / per, rem = t - grp * per;
+  const int tr = rem / tw_tiles;
+  TileCoord c;
+  c.b0 = grp * G::NI;
+  c.h0 = tr * G::TH;
+  c.w0 = (rem - tr * tw_tiles) * G::TW;
+  return c;
+}
+
+template <class G>
+static inline int num_tiles(int B, int H, int W) {
+  return ((B + G::NI - 1) / G::NI) * ((H + G::TH - 1) / G::TH) * ((W + G::TW - 1) / G::TW);
+}
+
+// offset (inside one channel's patch) of the top-left tap of tile pixel p
+template <class G, int KS>
+__device__ __forceinline__ int pix_off(int p) {
+  using P = Patch<G, KS>;
+  const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
+  const int r = rem / G::TW, c = rem % G::TW;
+  return (img * P::PH + r) * P::PWS + c;
+}
+
+// stage x[b0.., ci0..ci0+CK, h0-PAD.., w0-PAD..] (zero outside the tensor) into lds[ci][img][r][c]
+template <class G, int KS, int CK>
+__device__ __forceinline__ void stage_patch(const float* __restrict__ x, float* __restrict__ lds, const Shape& s, int C,
+                                            int ci0, TileCoord tc) {
+  using P = Patch<G, KS>;
+  constexpr int TOTAL = CK * G::NI * P::PH * P::PW;
+  for (int e = threadIdx.x; e < TOTAL; e += CT_THREADS) {
+    const int c = e % P::PW;
+    const int t1 = e / P::PW;
+    const int r = t1 % P::PH;
+    const int t2 = t1 / P::PH;
+    const int img = t2 % G::NI;
+    const int ci = t2 / G::NI;
+    const int b = tc.b0 + img, cc = ci0 + ci, hh = tc.h0 + r - P::PAD, ww = tc.w0 + c - P::PAD;
+    float v = 0.f;
+    if (b < s.B && cc < C && hh >= 0 && hh < s.H && ww >= 0 && ww < s.W)
+      v = x[(((int64_t)b * C + cc) * s.H + hh) * s.W + ww];
+    lds[ci * P::CIS + (img * P::PH + r) * P::PWS + c] = v;
+  }
+}
+
+// =========================================================================== forward / dgrad
+// CK input channels per chunk; filter slice in LDS as wl[(ci*KK + tap)][co] with row stride CTS.
+template <int KS> struct FwdCfg { static constexpr int CK = (KS == 3) ? 8 : 32; };
+
+template <int KS, int CT>
+struct WTile {
+  static constexpr int KK = KS * KS;
+  static constexpr int CK = FwdCfg<KS>::CK;
+  static constexpr int CTS = (CT % 32 == 16) ? CT : CT + 16;   // row stride % 32 == 16: two k-rows of a 32-lane group on disjoint banks
+  static constexpr int SIZE = CK * KK * CTS;
+};
+
+template <int KS, int CT, bool DGRAD>
+__device__ __forceinline__ void stage_weights(const float* __restrict__ w, float* __restrict__ wl, int Cin, int Cout, int ci0,
+                                              int co0) {
+  using WT = WTile<KS, CT>;
+  constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS;
+  constexpr int TOTAL = CT * CK * KK;
+  for (int e = threadIdx.x; e < TOTAL; e += CT_THREADS) {
+    int co, ci, tap;
+    int64_t src;
+    if (!DGRAD) {
+      // w[co][ci][tap]: for a fixed co the (ci, tap) run is contiguous
+      co = e / (CK * KK);
+      const int r = e - co * (CK * KK);
+      ci = r / KK;
+      tap = r - ci * KK;
+      src = ((int64_t)(co0 + co) * Cin + (ci0 + ci)) * KK + tap;
+    } else {
+      // effective filter weff[co][ci][tap] = w[ci][co][KK-1-tap] with w stored [Cin_eff][Cout_eff][KK]:
+      // for a fixed ci the (co, tap') run is contiguous
+      ci = e / (CT * KK);
+      const int r = e - ci * (CT * KK);
+      co = r / KK;
+      const int tp = r - co * KK;
+      tap = KK - 1 - tp;
+      src = ((int64_t)(ci0 + ci) * Cout + (co0 + co)) * KK + tp;
+    }
+    float v = 0.f;
+    if (co0 + co < Cout && ci0 + ci < Cin) v = w[src];
+    wl[(ci * KK + tap) * CTS + co] = v;
+  }
+}
+
+template <class G, int KS, int MF, int MT, bool DGRAD>
+__global__ void __launch_bounds__(CT_THREADS)
+conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                Shape s) {
+  using P = Patch<G, KS>;
+  constexpr int CT = MF * MT;
+  using WT = WTile<KS, CT>;
+  constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS;
+  constexpr int NT = 64 / MF;                 // pixel sub-tiles per wave (64 pixels per wave)
+  constexpr int KG = (MF == 32) ? 2 : 4;      // k values consumed per MFMA
+  __shared__ float lds[CK * P::CIS + WT::SIZE];
+  float* pl = lds;
+  float* wl = lds + CK * P::CIS;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % MF, h = lane / MF;     // MF=32: h in {0,1}; MF=16: h in {0..3}
+  const TileCoord tc = decode_tile<G>(blockIdx.x, s.H, s.W);
+  const int co0 = blockIdx.y * CT;
+
+  int lane_b[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) lane_b[n] = h * P::CIS + pix_off<G, KS>(wave * 64 + n * MF + j);
+  const int lane_a = (h * KK) * CTS + j;
+
+  using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
+  acc_t acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < (MF == 32 ? 16 : 4); ++r) acc[m][n][r] = 0.f;
+
+  for (int ci0 = 0; ci0 < s.Cin; ci0 += CK) {
+    __syncthreads();
+    stage_patch<G, KS, CK>(x, pl, s, s.Cin, ci0, tc);
+    stage_weights<KS, CT, DGRAD>(w, wl, s.Cin, s.Cout, ci0, co0);
+    __syncthreads();
+    // skip all-zero k-groups of a ragged last chunk (wave-uniform)
+    const int kgroups = (min(CK, s.Cin - ci0) + KG - 1) / KG;
+#pragma unroll
+    for (int g = 0; g < CK / KG; ++g) {
+      if (g < kgroups) {
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+          const int kh = tap / KS, kw = tap % KS;
+          float a[MT], b[NT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a[m] = wl[lane_a + ((g * KG) * KK + tap) * CTS + m * MF];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b[n] = pl[lane_b[n] + (g * KG) * P::CIS + kh * P::PWS + kw];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              if constexpr (MF == 32)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+              else
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
+      }
+    }
+  }
+
+  // epilogue: D[row = co][col = pixel]
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int p = wave * 64 + n * MF + j;
+    const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
+    const int b = tc.b0 + img, hh = tc.h0 + rem / G::TW, ww = tc.w0 + rem % G::TW;
+    if (b >= s.B || hh >= s.H || ww >= s.W) continue;
+    const int64_t base = ((int64_t)b * s.Cout * s.H + hh) * s.W + ww;
+    const int64_t cstride = (int64_t)s.H * s.W;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < (MF == 32 ? 16 : 4); ++r) {
+        const int row = (MF == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * h) : (h * 4 + r);
+        const int co = co0 + m * MF + row;
+        if (co < s.Cout) y[base + co * cstride] = acc[m][n][r] + (bias ? bias[co] : 0.f);
+      }
+    }
+  }
+}
+
+// =========================================================================== wgrad
+template <int KS> struct WgCfg {
+  static constexpr int CKW = (KS == 3) ? 16 : 32;      // input channels per workgroup
+  static constexpr int KK = KS * KS;
+  static constexpr int NCOL = CKW * KK;                // (ci, tap) columns
+  static constexpr int NT = (NCOL + 15) / 16;
+};
+constexpr int WG_GYS = 256 + 2;    // gy tile row stride: 16 co x 2 pixels of a 32-lane group hit 32 distinct banks
+
+template <class G, int KS, int MTW>
+__global__ void __launch_bounds__(CT_THREADS)
+conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, Shape s, int ntiles, int S) {
+  using P = Patch<G, KS>;
+  using C = WgCfg<KS>;
+  constexpr int CKW = C::CKW, KK = C::KK, NT = C::NT, CT = 16 * MTW;
+  constexpr int PATCH = CKW * P::CIS, GYT = CT * WG_GYS;
+  constexpr int RED = 4 * MTW * NT * 4 * 64;           // cross-wave reduction: 4 waves x (MTW*NT*4 regs) x 64 lanes
+  constexpr int LDS_FLOATS = (PATCH + GYT) > RED ? (PATCH + GYT) : RED;
+  __shared__ float lds[LDS_FLOATS];
+  float* pl = lds;
+  float* gl = lds + PATCH;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, h = lane >> 4;
+  const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CKW;
+  const int split = blockIdx.x;
+
+  // B operand: column j of N-tile n -> (ci, tap) -> patch offset; plus this lane's pixel within the k-group
+  int colbase[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = n * 16 + j;
+    const int ci = col / KK, tap = col % KK;
+    colbase[n] = (col < C::NCOL) ? (ci * P::CIS + (tap / KS) * P::PWS + (tap % KS)) : 0;
+  }
+  const int lane_b = pix_off<G, KS>(wave * 64) + h;                // + const(g) below
+  const int lane_a = j * WG_GYS + wave * 64 + h;                    // + m*16*GYS + 4g
+
+  f32x4 acc[MTW][NT];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int t = split; t < ntiles; t += S) {
+    const TileCoord tc = decode_tile<G>(t, s.H, s.W);
+    __syncthreads();
+    stage_patch<G, KS, CKW>(x, pl, s, s.Cin, ci0, tc);
+    // gy tile: gl[co][p]
+    for (int e = threadIdx.x; e < CT * 256; e += CT_THREADS) {
+      const int p = e & 255, co = e >> 8;
+      const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
+      const int b = tc.b0 + img, hh = tc.h0 + rem / G::TW, ww = tc.w0 + rem % G::TW;
+      float v = 0.f;
+      if (b < s.B && hh < s.H && ww < s.W && co0 + co < s.Cout)
+        v = gy[(((int64_t)b * s.Cout + co0 + co) * s.H + hh) * s.W + ww];
+      gl[co * WG_GYS + p] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      // pixel group 64*wave + 4g .. +3: same row (TW % 4 == 0); offset relative to the wave's first pixel
+      constexpr int PPI = G::TH * G::TW;
+      const int pg = 4 * g;                                   // < 64
+      const int goff = ((pg / PPI) * P::PH + (pg % PPI) / G::TW) * P::PWS + (pg % G::TW);
+      float a[MTW], b[NT];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) a[m] = gl[lane_a + m * 16 * WG_GYS + 4 * g];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[n] = pl[colbase[n] + lane_b + goff];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+  }
+
+  // cross-wave reduction through LDS (fixed order), then one partial write per workgroup
+  __syncthreads();
+  float* red = lds;                                            // [wave][m][n][r][lane]
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((wave * MTW + m) * NT + n) * 4 + r) * 64 + lane] = acc[m][n][r];
+  __syncthreads();
+  constexpr int PER_WAVE = MTW * NT * 4 * 64;
+  for (int e = threadIdx.x; e < PER_WAVE; e += CT_THREADS) {
+    const float v = (red[e] + red[PER_WAVE + e]) + (red[2 * PER_WAVE + e] + red[3 * PER_WAVE + e]);
+    const int l = e & 63, q = e >> 6;
+    const int r = q & 3, n = (q >> 2) % NT, m = (q >> 2) / NT;
+    const int col = n * 16 + (l & 15);
+    const int co = co0 + m * 16 + (l >> 4) * 4 + r;
+    const int ci = ci0 + col / KK, tap = col % KK;
+    if (col < C::NCOL && co < s.Cout && ci < s.Cin)
+      part[(((int64_t)split * s.Cout + co) * s.Cin + ci) * KK + tap] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int64_t E, int S) {
+  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < E; e += gridDim.x * 256ll) {
+    float acc = 0.f;
+    for (int sidx = 0; sidx < S; ++sidx) acc += part[sidx * E + e];
+    gw[e] = acc;
+  }
+}
+
+// =========================================================================== host dispatch
+enum GeoId { GEO_4, GEO_8, GEO_16, GEO_X };
+static inline GeoId pick_geo(int H, int W) {
+  if (H == 4 && W == 4) return GEO_4;
+  if (H == 8 && W == 8) return GEO_8;
+  if (H == 16 && W == 16) return GEO_16;
+  return GEO_X;
+}
+static inline int geo_tiles(GeoId g, int B, int H, int W) {
+  switch (g) {
+    case GEO_4: return num_tiles<G4>(B, H, W);
+    case GEO_8: return num_tiles<G8>(B, H, W);
+    case GEO_16: return num_tiles<G16>(B, H, W);
+    default: return num_tiles<GX>(B, H, W);
+  }
+}
+
+template <class G, int KS, bool DGRAD>
+int launch_fwd_geo(const float* x, const float* w, const float* bias, float* y, Shape s, hipStream_t st) {
+  const int tiles = num_tiles<G>(s.B, s.H, s.W);
+  // MFMA flavour: 32x32x2 when the output-channel count fills (or nearly fills) 32-row tiles, else 16x16x4
+  const bool use32 = (s.Cout % 32 == 0) || s.Cout > 48;
+  if (use32) {
+    if (s.Cout > 32) {
+      dim3 grid(tiles, (s.Cout + 63) / 64);
+      conv_fwd_kernel<G, KS, 32, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s);
+    } else {
+      dim3 grid(tiles, 1);
+      conv_fwd_kernel<G, KS, 32, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s);
+    }
+  } else {
+    if (s.Cout > 16) {
+      dim3 grid(tiles, (s.Cout + 31) / 32);
+      conv_fwd_kernel<G, KS, 16, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s);
+    } else {
+      dim3 grid(tiles, 1);
+      conv_fwd_kernel<G, KS, 16, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s);
+    }
+  }
+  return tg_launch_status();
+}
+
+template <int KS, bool DGRAD>
+int launch_fwd(const float* x, const float* w, const float* bias, float* y, Shape s, hipStream_t st) {
+  switch (pick_geo(s.H, s.W)) {
+    case GEO_4: return launch_fwd_geo<G4, KS, DGRAD>(x, w, bias, y, s, st);
+    case GEO_8: return launch_fwd_geo<G8, KS, DGRAD>(x, w, bias, y, s, st);
+    case GEO_16: return launch_fwd_geo<G16, KS, DGRAD>(x, w, bias, y, s, st);
+    default: return launch_fwd_geo<GX, KS, DGRAD>(x, w, bias, y, s, st);
+  }
+}
+
+struct WgPlan {
+  int tiles, co_tiles, ci_chunks, S, mtw;
+};
+static inline WgPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int ks) {
+  WgPlan p;
+  p.tiles = geo_tiles(pick_geo(H, W), B, H, W);
+  p.mtw = Cout > 16 ? 2 : 1;
+  p.co_tiles = (Cout + 16 * p.mtw - 1) / (16 * p.mtw);
+  const int ckw = (ks == 3) ? WgCfg<3>::CKW : WgCfg<1>::CKW;
+  p.ci_chunks = (Cin + ckw - 1) / ckw;
+  const int groups = p.co_tiles * p.ci_chunks;
+  int S = 1024 / groups;
+  if (S < 1) S = 1;
+  if (S > p.tiles) S = p.tiles;
+  p.S = S;
+  return p;
+}
+
+template <class G, int KS>
+int launch_wgrad_geo(const float* x, const float* gy, float* part, Shape s, const WgPlan& p, hipStream_t st) {
+  dim3 grid(p.S, p.co_tiles, p.ci_chunks);
+  if (p.mtw == 2) conv_wgrad_kernel<G, KS, 2><<<grid, CT_THREADS, 0, st>>>(x, gy, part, s, p.tiles, p.S);
+  else conv_wgrad_kernel<G, KS, 1><<<grid, CT_THREADS, 0, st>>>(x, gy, part, s, p.tiles, p.S);
+  return tg_launch_status();
+}
+
+template <int KS>
+int launch_wgrad(const float* x, const float* gy, float* part, Shape s, const WgPlan& p, hipStream_t st) {
+  switch (pick_geo(s.H, s.W)) {
+    case GEO_4: return launch_wgrad_geo<G4, KS>(x, gy, part, s, p, st);
+    case GEO_8: return launch_wgrad_geo<G8, KS>(x, gy, part, s, p, st);
+    case GEO_16: return launch_wgrad_geo<G16, KS>(x, gy, part, s, p, st);
+    default: return launch_wgrad_geo<GX, KS>(x, gy, part, s, p, st);
+  }
+}
+
+static inline int check_shape(int B, int Cin, int Cout, int H, int W, int ks) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return TG_EINVAL;
+  if (ks != 1 && ks != 3) return TG_EUNSUPPORTED;
+  if ((int64_t)B * (Cin > Cout ? Cin : Cout) * H * W >= (1ll << 40)) return TG_EUNSUPPORTED;
+  return TG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int ks,
+                  void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(w); TG_CHECK_PTR(y);
+  if (int rc = check_shape(B, Cin, Cout, H, W, ks)) return rc;
+  Shape s{B, Cin, Cout, H, W};
+  return ks == 3 ? launch_fwd<3, false>(x, w, bias, y, s, tg_stream(stream)) : launch_fwd<1, false>(x, w, bias, y, s, tg_stream(stream));
+}
+
+int tg_conv2d_dgrad(const float* gy, const float* w, float* gx, int B, int Cin, int Cout, int H, int W, int ks, void* stream) {
+  TG_CHECK_PTR(gy); TG_CHECK_PTR(w); TG_CHECK_PTR(gx);
+  if (int rc = check_shape(B, Cin, Cout, H, W, ks)) return rc;
+  // a forward convolution whose input channels are the original Cout and output channels the original Cin
+  Shape s{B, Cout, Cin, H, W};
+  return ks == 3 ? launch_fwd<3, true>(gy, w, nullptr, gx, s, tg_stream(stream)) : launch_fwd<1, true>(gy, w, nullptr, gx, s, tg_stream(stream));
+}
+
+size_t tg_conv2d_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ks) {
+  if (check_shape(B, Cin, Cout, H, W, ks) != TG_OK) return 0;
+  const WgPlan p = wgrad_plan(B, Cin, Cout, H, W, ks);
+  return (size_t)p.S * Cout * Cin * ks * ks * sizeof(float);
+}
+
+int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* workspace, size_t workspace_bytes, int B, int Cin,
+                    int Cout, int H, int W, int ks, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(gy); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
+  if (int rc = check_shape(B, Cin, Cout, H, W, ks)) return rc;
+  if (workspace_bytes < tg_conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks)) return TG_EWORKSPACE;
+  const WgPlan p = wgrad_plan(B, Cin, Cout, H, W, ks);
+  Shape s{B, Cin, Cout, H, W};
+  hipStream_t st = tg_stream(stream);
+  const int rc = ks == 3 ? launch_wgrad<3>(x, gy, workspace, s, p, st) : launch_wgrad<1>(x, gy, workspace, s, p, st);
+  if (rc != TG_OK) return rc;
+  const int64_t E = (int64_t)Cout * Cin * ks * ks;
+  wgrad_reduce_kernel<<<tg_ew_grid(E, 256), 256, 0, st>>>(workspace, gw, E, p.S);
+  return tg_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// NCHW "plane" iteration helpers shared by the BatchNorm and channel-reduction kernels.
+//
+// A plane is one (b, c) image: HW contiguous floats at (b*C + c)*HW.  Two regimes:
+//   big   (HW % 4 == 0 && HW >= 1024): 16-byte accesses, no per-element integer division;
+//   small (everything else)          : flat index, one division per element (these tensors
+//                                      are at most a few MB, the kernels are launch-bound).
+#pragma once
+#include "common.h"
+
+namespace planes {
+
+constexpr int BLOCK = 256;
+constexpr int TILE = BLOCK * 4;   // floats per block-tile in the big regime
+
+static inline bool big(int HW) { return (HW % 4 == 0) && HW >= TILE; }
+
+// ------------------------------------------------------------------ elementwise over planes
+// Body: __device__ void init(int c)                       -- per-block channel constants
+//       __device__ void vec4(int c, int64_t off)          -- process 4 floats at off
+//       __device__ void one(int c, int64_t off)           -- process 1 float at off
+template <class Body>
+__global__ void __launch_bounds__(BLOCK) map_big(Body body, int C, int HW) {
+  const int plane = blockIdx.x;
+  const int c = plane % C;
+  const int p = (blockIdx.y * BLOCK + threadIdx.x) * 4;
+  if (p < HW) body.vec4(c, (int64_t)plane * HW + p);
+}
+template <class Body>
+__global__ void __launch_bounds__(BLOCK) map_flat(Body body, int C, int HW, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < total; i += gridDim.x * (int64_t)BLOCK) {
+    const int c = (int)((i / HW) % C);
+    body.one(c, i);
+  }
+}
+template <class Body>
+static inline void launch_map(Body body, int B, int C, int HW, hipStream_t st, bool aligned = true) {
+  if (big(HW) && aligned) {
+    dim3 grid(B * C, (HW + TILE - 1) / TILE);
+    map_big<Body><<<grid, BLOCK, 0, st>>>(body, C, HW);
+  } else {
+    const int64_t total = (int64_t)B * C * HW;
+    map_flat<Body><<<tg_ew_grid(total, BLOCK), BLOCK, 0, st>>>(body, C, HW, total);
+  }
+}
+
+// ------------------------------------------------------------------ per-channel reductions, stage 1
+// Number of partial blocks per channel (must agree between workspace sizing and launch).
+static inline int splits(int B, int C, int HW) {
+  const int64_t n = (int64_t)B * HW;
+  int64_t units = (n + TILE - 1) / TILE;
+  int64_t cap = 2048 / (C > 0 ? C : 1);
+  if (cap < 1) cap = 1;
+  // aim for >= 4 tiles per block so that per-thread partial sums stay short
+  int64_t s = (units + 3) / 4;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+// Red: static constexpr int K (values per element);
+//      __device__ void init(int c);
+//      __device__ void acc4(int64_t off, float* a /*K*/);   accumulate 4 elements
+//      __device__ void acc1(int64_t off, float* a);
+// partial layout: [C][S][K] doubles.
+template <class Red>
+__global__ void __launch_bounds__(BLOCK) reduce_stage1(Red red, double* __restrict__ partial, int B, int C, int HW, int S, int is_big) {
+  constexpr int K = Red::K;
+  __shared__ double scratch[32];
+  const int c = blockIdx.x, s = blockIdx.y;
+  float a[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) a[k] = 0.f;
+  red.init(c);
+  if (is_big) {
+    const int tiles_per_row = (HW + TILE - 1) / TILE;
+    const int T = B * tiles_per_row;
+    for (int t = s; t < T; t += S) {
+      const int b = t / tiles_per_row;
+      const int p = (t - b * tiles_per_row) * TILE + threadIdx.x * 4;
+      if (p < HW) red.acc4(((int64_t)b * C + c) * HW + p, a);
+    }
+  } else {
+    const int64_t n = (int64_t)B * HW;
+    for (int64_t e = (int64_t)s * BLOCK + threadIdx.x; e < n; e += (int64_t)S * BLOCK) {
+      const int64_t b = e / HW;
+      const int64_t p = e - b * HW;
+      red.acc1((b * C + c) * HW + p, a);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double r = block_sum_d((double)a[k], scratch);
+    if (threadIdx.x == 0) partial[((int64_t)c * S + s) * K + k] = r;
+  }
+}
+
+template <class Red>
+static inline void launch_reduce(Red red, double* partial, int B, int C, int HW, hipStream_t st, bool aligned = true) {
+  const int S = splits(B, C, HW);
+  dim3 grid(C, S);
+  reduce_stage1<Red><<<grid, BLOCK, 0, st>>>(red, partial, B, C, HW, S, (big(HW) && aligned) ? 1 : 0);
+}
+
+// helper for stage 2 kernels: sum the S partials of value k of channel c
+__device__ __forceinline__ double gather(const double* __restrict__ partial, int c, int S, int K, int k) {
+  double r = 0.0;
+  for (int s = 0; s < S; ++s) r += partial[((int64_t)c * S + s) * K + k];
+  return r;
+}
+
+}  // namespace planes

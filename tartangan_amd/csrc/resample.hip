@@ -1,0 +1,260 @@
+// Resampling kernels (all HBM-bound, gather form, no atomics):
+//   up2x / pool2            nearest x2 upsample <-> 2x2 sum-pool (transposes of each other)
+//   bilinear_half fwd/bwd   F.interpolate(scale .5, bilinear, align_corners=True) and its transpose
+//   maxpool2 fwd/bwd/gather 2x2 max-pool with argmax byte, scatter and gather by argmax
+#include "common.h"
+
+namespace {
+
+constexpr int RS_BLOCK = 256;
+
+// ------------------------------------------------------------------ up2x / pool2
+// vector path: one thread per input PAIR (w, w+1) -> two float4 stores (rows 2h, 2h+1)
+__global__ void __launch_bounds__(RS_BLOCK) up2x_vec(const float* __restrict__ x, float* __restrict__ y, float alpha,
+                                                     int64_t npairs, int H, int W2 /* = W/2 */) {
+  for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < npairs; i += gridDim.x * (int64_t)RS_BLOCK) {
+    const int64_t row = i / W2;            // bc*H + h
+    const int wp = (int)(i - row * W2);
+    const float2 v = *reinterpret_cast<const float2*>(x + row * (2 * W2) + 2 * wp);
+    const float a = alpha * v.x, b = alpha * v.y;
+    const float4 o = make_float4(a, a, b, b);
+    // output row index = 2*row (since (bc*2H + 2h) = 2*(bc*H + h)), width 4*W2
+    float* dst = y + (2 * row) * (int64_t)(4 * W2) + 4 * wp;
+    *reinterpret_cast<float4*>(dst) = o;
+    *reinterpret_cast<float4*>(dst + 4 * W2) = o;
+  }
+}
+__global__ void __launch_bounds__(RS_BLOCK) up2x_scalar(const float* __restrict__ x, float* __restrict__ y, float alpha,
+                                                        int64_t nout, int H, int W) {
+  const int OW = 2 * W, OH = 2 * H;
+  for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < nout; i += gridDim.x * (int64_t)RS_BLOCK) {
+    const int ow = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    const int64_t bc = t / OH;
+    y[i] = alpha * x[(bc * H + (oh >> 1)) * W + (ow >> 1)];
+  }
+}
+
+// vector path: one thread per output PAIR: float4 from row 2h and row 2h+1
+__global__ void __launch_bounds__(RS_BLOCK) pool2_vec(const float* __restrict__ x, float* __restrict__ y, float alpha,
+                                                      int64_t npairs, int OW2 /* = W/4 */) {
+  for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < npairs; i += gridDim.x * (int64_t)RS_BLOCK) {
+    const int64_t orow = i / OW2;          // bc*OH + oh
+    const int op = (int)(i - orow * OW2);
+    const float* src = x + (2 * orow) * (int64_t)(4 * OW2) + 4 * op;
+    const float4 r0 = *reinterpret_cast<const float4*>(src);
+    const float4 r1 = *reinterpret_cast<const float4*>(src + 4 * OW2);
+    float2 o;
+    o.x = alpha * ((r0.x + r0.y) + (r1.x + r1.y));
+    o.y = alpha * ((r0.z + r0.w) + (r1.z + r1.w));
+    *reinterpret_cast<float2*>(y + orow * (int64_t)(2 * OW2) + 2 * op) = o;
+  }
+}
+__global__ void __launch_bounds__(RS_BLOCK) pool2_scalar(const float* __restrict__ x, float* __restrict__ y, float alpha,
+                                                         int64_t nout, int H, int W) {
+  const int OW = W / 2, OH = H / 2;
+  for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < nout; i += gridDim.x * (int64_t)RS_BLOCK) {
+    const int ow = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    const int64_t bc = t / OH;
+    const float* s = x + (bc * H + 2 * oh) * W + 2 * ow;
+    y[i] = alpha * ((s[0] + s[1]) + (s[W] + s[W + 1]));
+  }
+}
+
+// ------------------------------------------------------------------ bilinear half (align_corners = True)
+// ATen's source-index computation in fp32 (UpSample.h area_pixel_compute_source_index, align_corners)
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp src_index(int o, float scale, int in_size) {
+  const float r = scale * (float)o;
+  Lerp t;
+  t.i0 = (int)r;
+  if (t.i0 > in_size - 1) t.i0 = in_size - 1;
+  t.i1 = t.i0 + ((t.i0 < in_size - 1) ? 1 : 0);
+  t.l1 = r - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+
+__global__ void __launch_bounds__(RS_BLOCK) bilinear_half_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                     int64_t nout, int H, int W, int OH, int OW, float sh, float sw) {
+  for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < nout; i += gridDim.x * (int64_t)RS_BLOCK) {
+    const int ow = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    const int64_t bc = t / OH;
+    const Lerp a = src_index(oh, sh, H), b = src_index(ow, sw, W);
+    const float* p = x + bc * (int64_t)H * W;
+    const float top = b.l0 * p[a.i0 * W + b.i0] + b.l1 * p[a.i0 * W + b.i1];
+    const float bot = b.l0 * p[a.i1 * W + b.i0] + b.l1 * p[a.i1 * W + b.i1];
+    y[i] = a.l0 * top + a.l1 * bot;
+  }
+}
+
+// weight with which output index o reads input index `in` along one axis
+__device__ __forceinline__ float axis_weight(int o, int in, float scale, int in_size) {
+  const Lerp t = src_index(o, scale, in_size);
+  float w = 0.f;
+  if (t.i0 == in) w += t.l0;
+  if (t.i1 == in) w += t.l1;
+  return w;
+}
+
+__global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                                     int64_t nin, int H, int W, int OH, int OW, float sh, float sw) {
+  for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < nin; i += gridDim.x * (int64_t)RS_BLOCK) {
+    const int w = (int)(i % W);
+    const int64_t t = i / W;
+    const int h = (int)(t % H);
+    const int64_t bc = t / H;
+    // outputs o with floor(scale*o) in {in-1, in}: a short candidate window, tested exactly
+    int oh_lo = sh > 0.f ? (int)((float)(h - 1) / sh) - 1 : 0, oh_hi = sh > 0.f ? (int)((float)(h + 1) / sh) + 1 : OH - 1;
+    int ow_lo = sw > 0.f ? (int)((float)(w - 1) / sw) - 1 : 0, ow_hi = sw > 0.f ? (int)((float)(w + 1) / sw) + 1 : OW - 1;
+    oh_lo = oh_lo < 0 ? 0 : oh_lo; ow_lo = ow_lo < 0 ? 0 : ow_lo;
+    oh_hi = oh_hi > OH - 1 ? OH - 1 : oh_hi; ow_hi = ow_hi > OW - 1 ? OW - 1 : ow_hi;
+    const float* g = gy + bc * (int64_t)OH * OW;
+    float acc = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const float wh = axis_weight(oh, h, sh, H);
+      if (wh == 0.f) continue;
+      float racc = 0.f;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const float ww = axis_weight(ow, w, sw, W);
+        if (ww != 0.f) racc += ww * g[oh * OW + ow];
+      }
+      acc += wh * racc;
+    }
+    gx[i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ 2x2 max pool
+__global__ void __launch_bounds__(RS_BLOCK) maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                uint8_t* __restrict__ idx, int64_t nout, int H, int W) {
+  const int OW = W / 2, OH = H / 2;
+  for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < nout; i += gridDim.x * (int64_t)RS_BLOCK) {
+    const int ow = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    const int64_t bc = t / OH;
+    const float* s = x + (bc * H + 2 * oh) * W + 2 * ow;
+    const float v[4] = {s[0], s[1], s[W], s[W + 1]};
+    float m = v[0];
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+      if (v[j] > m || v[j] != v[j]) { m = v[j]; k = j; }     // first maximum wins; NaN propagates like ATen
+    y[i] = m;
+    idx[i] = (uint8_t)k;
+  }
+}
+
+__global__ void __launch_bounds__(RS_BLOCK) maxpool2_bwd_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ idx,
+                                                                float* __restrict__ gx, int64_t nout, int H, int W) {
+  const int OW = W / 2, OH = H / 2;
+  for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < nout; i += gridDim.x * (int64_t)RS_BLOCK) {
+    const int ow = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    const int64_t bc = t / OH;
+    float* d = gx + (bc * H + 2 * oh) * W + 2 * ow;
+    const float g = gy[i];
+    const int k = idx[i];
+    *reinterpret_cast<float2*>(d) = make_float2(k == 0 ? g : 0.f, k == 1 ? g : 0.f);
+    *reinterpret_cast<float2*>(d + W) = make_float2(k == 2 ? g : 0.f, k == 3 ? g : 0.f);
+  }
+}
+
+__global__ void __launch_bounds__(RS_BLOCK) maxpool2_gather_kernel(const float* __restrict__ x, const uint8_t* __restrict__ idx,
+                                                                   float* __restrict__ y, int64_t nout, int H, int W) {
+  const int OW = W / 2, OH = H / 2;
+  for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < nout; i += gridDim.x * (int64_t)RS_BLOCK) {
+    const int ow = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    const int64_t bc = t / OH;
+    const int k = idx[i];
+    y[i] = x[(bc * H + 2 * oh + (k >> 1)) * W + 2 * ow + (k & 1)];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_up2x(const float* x, float* y, float alpha, int BC, int H, int W, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(y); TG_CHECK_POS(BC); TG_CHECK_POS(H); TG_CHECK_POS(W);
+  hipStream_t st = tg_stream(stream);
+  if (W % 2 == 0 && tg_aligned16(y) && ((uintptr_t)x & 7) == 0) {
+    const int64_t npairs = (int64_t)BC * H * (W / 2);
+    up2x_vec<<<tg_ew_grid(npairs, RS_BLOCK), RS_BLOCK, 0, st>>>(x, y, alpha, npairs, H, W / 2);
+  } else {
+    const int64_t nout = (int64_t)BC * H * W * 4;
+    up2x_scalar<<<tg_ew_grid(nout, RS_BLOCK), RS_BLOCK, 0, st>>>(x, y, alpha, nout, H, W);
+  }
+  return tg_launch_status();
+}
+
+int tg_pool2(const float* x, float* y, float alpha, int BC, int H, int W, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(y); TG_CHECK_POS(BC); TG_CHECK_POS(H); TG_CHECK_POS(W);
+  if ((H & 1) || (W & 1)) return TG_EUNSUPPORTED;
+  hipStream_t st = tg_stream(stream);
+  if (W % 4 == 0 && tg_aligned16(x) && ((uintptr_t)y & 7) == 0) {
+    const int64_t npairs = (int64_t)BC * (H / 2) * (W / 4);
+    pool2_vec<<<tg_ew_grid(npairs, RS_BLOCK), RS_BLOCK, 0, st>>>(x, y, alpha, npairs, W / 4);
+  } else {
+    const int64_t nout = (int64_t)BC * (H / 2) * (W / 2);
+    pool2_scalar<<<tg_ew_grid(nout, RS_BLOCK), RS_BLOCK, 0, st>>>(x, y, alpha, nout, H, W);
+  }
+  return tg_launch_status();
+}
+
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+int tg_bilinear_half_fwd(const float* x, float* y, int BC, int H, int W, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(y); TG_CHECK_POS(BC);
+  if (H < 2 || W < 2) return TG_EUNSUPPORTED;
+  const int OH = H / 2, OW = W / 2;
+  const int64_t nout = (int64_t)BC * OH * OW;
+  bilinear_half_fwd_kernel<<<tg_ew_grid(nout, RS_BLOCK), RS_BLOCK, 0, tg_stream(stream)>>>(x, y, nout, H, W, OH, OW,
+                                                                                          ac_scale(H, OH), ac_scale(W, OW));
+  return tg_launch_status();
+}
+
+int tg_bilinear_half_bwd(const float* gy, float* gx, int BC, int H, int W, void* stream) {
+  TG_CHECK_PTR(gy); TG_CHECK_PTR(gx); TG_CHECK_POS(BC);
+  if (H < 2 || W < 2) return TG_EUNSUPPORTED;
+  const int OH = H / 2, OW = W / 2;
+  const int64_t nin = (int64_t)BC * H * W;
+  bilinear_half_bwd_kernel<<<tg_ew_grid(nin, RS_BLOCK), RS_BLOCK, 0, tg_stream(stream)>>>(gy, gx, nin, H, W, OH, OW,
+                                                                                         ac_scale(H, OH), ac_scale(W, OW));
+  return tg_launch_status();
+}
+
+int tg_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int BC, int H, int W, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(y); TG_CHECK_PTR(idx); TG_CHECK_POS(BC);
+  if (H < 2 || W < 2 || (H & 1) || (W & 1)) return TG_EUNSUPPORTED;
+  const int64_t nout = (int64_t)BC * (H / 2) * (W / 2);
+  maxpool2_fwd_kernel<<<tg_ew_grid(nout, RS_BLOCK), RS_BLOCK, 0, tg_stream(stream)>>>(x, y, idx, nout, H, W);
+  return tg_launch_status();
+}
+
+int tg_maxpool2_bwd(const float* gy, const uint8_t* idx, float* gx, int BC, int H, int W, void* stream) {
+  TG_CHECK_PTR(gy); TG_CHECK_PTR(idx); TG_CHECK_PTR(gx); TG_CHECK_POS(BC);
+  if (H < 2 || W < 2 || (H & 1) || (W & 1) || ((uintptr_t)gx & 7)) return TG_EUNSUPPORTED;
+  const int64_t nout = (int64_t)BC * (H / 2) * (W / 2);
+  maxpool2_bwd_kernel<<<tg_ew_grid(nout, RS_BLOCK), RS_BLOCK, 0, tg_stream(stream)>>>(gy, idx, gx, nout, H, W);
+  return tg_launch_status();
+}
+
+int tg_maxpool2_gather(const float* x, const uint8_t* idx, float* y, int BC, int H, int W, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(idx); TG_CHECK_PTR(y); TG_CHECK_POS(BC);
+  if (H < 2 || W < 2 || (H & 1) || (W & 1)) return TG_EUNSUPPORTED;
+  const int64_t nout = (int64_t)BC * (H / 2) * (W / 2);
+  maxpool2_gather_kernel<<<tg_ew_grid(nout, RS_BLOCK), RS_BLOCK, 0, tg_stream(stream)>>>(x, idx, y, nout, H, W);
+  return tg_launch_status();
+}
+
+}  // extern "C"

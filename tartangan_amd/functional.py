@@ -110,7 +110,7 @@ class _ChannelSum(Function):
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         out = x.new_empty(C)
-        K().channel_sum(x, out, B, C, hw)
+        K().channel_sum(x, out, _ws(x, K().bn_workspace(B, C, hw)), B, C, hw)
         ctx.shape = x.shape
         return out
 

@@ -45,7 +45,7 @@ class FusedAdam:
 
     The step-dependent scalars (lr / bias_correction1, sqrt(bias_correction2)) are
     computed on the host in double precision like torch's single-tensor path and
-    handed to the kernel through a 4-float device buffer, so a captured HIP graph
+    handed to the kernel through a 6-float device buffer, so a captured HIP graph
     of the step stays valid for every step index.
     """
 
@@ -56,8 +56,8 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
-        self._hyper = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
-        self._hyper_host = torch.zeros(4, dtype=torch.float32)
+        self._hyper = torch.zeros(6, dtype=torch.float32, device=self.flat.device)
+        self._hyper_host = torch.zeros(6, dtype=torch.float32)
         if self.flat.is_cuda:
             self._hyper_host = self._hyper_host.pin_memory()
 
@@ -71,7 +71,7 @@ class FusedAdam:
         bc1 = 1 - b1 ** self.step_count
         bc2 = 1 - b2 ** self.step_count
         h = self._hyper_host
-        h[0], h[1], h[2], h[3] = self.lr / bc1, math.sqrt(bc2), b1, b2
+        h[0], h[1], h[2], h[3], h[4], h[5] = self.lr / bc1, math.sqrt(bc2), b1, b2, 1 - b1, 1 - b2
         self._hyper.copy_(h, non_blocking=True)
 
     def apply(self):

@@ -39,7 +39,7 @@ class Emulator:
                                              _v(gy, B, Cout, H, W), padding=ks // 2))
         return 0
 
-    def channel_sum(self, x, out, B, C, HW):
+    def channel_sum(self, x, out, ws, B, C, HW):
         out.copy_(_v(x, B, C, HW).sum((0, 2)))
         return 0
 
@@ -287,7 +287,7 @@ class Emulator:
 
     # ---------------------------------------------------------------- optimiser
     def adam_step(self, p, g, m, v, hyper, eps, n):
-        step_size, bc2_sqrt, b1, b2 = [float(h) for h in hyper]
+        step_size, bc2_sqrt, b1, b2 = [float(h) for h in hyper[:4]]
         m.lerp_(g, 1 - b1)
         v.mul_(b2).addcmul_(g, g, value=1 - b2)
         denom = (v.sqrt() / bc2_sqrt).add_(eps)

@@ -1,0 +1,257 @@
+"""Per-entry-point parity: every HIP kernel behind include/tartangan_amd.h against the
+reference semantics in tests/emulator.py, on identical seeded inputs, through the C ABI."""
+import pytest
+import torch
+
+from emulator import Emulator
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    from tartangan_amd import backend
+    backend._set_backend_for_testing(None)
+    return backend.get()
+
+
+E = Emulator()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + 1000 * len(shape) + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def run_both(K, name, args, outs, tol=1e-5, atol=None):
+    """args: list of python scalars / CPU tensors / None; outs: indices of output tensors."""
+    cpu = [a.clone() if torch.is_tensor(a) else a for a in args]
+    dev = [a.cuda() if torch.is_tensor(a) else a for a in args]
+    getattr(E, name)(*cpu)
+    getattr(K, name)(*dev)
+    torch.cuda.synchronize()
+    for i in outs:
+        want, got = cpu[i].float(), dev[i].cpu().float()
+        scale = float(want.abs().max()) if want.numel() else 1.0
+        err = float((want - got).abs().max()) if want.numel() else 0.0
+        lim = (atol if atol is not None else tol * max(scale, 1e-6))
+        assert err <= lim, f'{name} arg{i}: max err {err:.3e} > {lim:.3e} (scale {scale:.3e})'
+    for i, a in enumerate(args):      # inputs must not be modified
+        if torch.is_tensor(a) and i not in outs:
+            assert torch.equal(dev[i].cpu(), a), f'{name} modified input {i}'
+
+
+CONV_SHAPES = [
+    # B, Cin, Cout, H, W, ks
+    (3, 3, 16, 32, 32, 3), (2, 16, 16, 64, 64, 3), (5, 32, 16, 32, 32, 3), (2, 64, 32, 16, 16, 3),
+    (20, 128, 128, 4, 4, 3), (6, 128, 64, 8, 8, 3), (2, 128, 128, 16, 16, 3), (1, 16, 3, 64, 64, 1),
+    (2, 3, 16, 40, 24, 1), (3, 128, 16, 16, 16, 1), (2, 100, 120, 8, 8, 3), (2, 8, 4, 32, 32, 3),
+    (1, 4, 1, 16, 16, 1), (2, 16, 3, 20, 36, 3), (2, 32, 64, 32, 32, 1), (1, 64, 128, 16, 16, 1),
+    (17, 16, 48, 4, 4, 1), (2, 32, 32, 128, 128, 3),
+]
+
+
+@pytest.mark.parametrize('shape', CONV_SHAPES)
+def test_conv_fwd(K, shape):
+    B, Cin, Cout, H, W, ks = shape
+    x, w, b = rnd(B, Cin, H, W), rnd(Cout, Cin, ks, ks, scale=0.2), rnd(Cout)
+    run_both(K, 'conv2d_fwd', [x, w, b, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, ks], [3], tol=2e-5)
+    run_both(K, 'conv2d_fwd', [x, w, None, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, ks], [3], tol=2e-5)
+
+
+def test_conv_fwd_exact_integer_layout(K):
+    """Asymmetric small-integer data: any A/B/C fragment transposition shows up as an exact mismatch."""
+    B, Cin, Cout, H, W = 2, 8, 32, 32, 32
+    x = (torch.arange(B * Cin * H * W) % 7 - 3).float().view(B, Cin, H, W)
+    w = (torch.arange(Cout * Cin * 9) % 5 - 2).float().view(Cout, Cin, 3, 3)
+    run_both(K, 'conv2d_fwd', [x, w, None, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, 3], [3], atol=0.0)
+    run_both(K, 'conv2d_dgrad', [torch.round(rnd(B, Cout, H, W) * 2), w, torch.zeros(B, Cin, H, W), B, Cin, Cout, H, W, 3],
+             [2], atol=0.0)
+
+
+@pytest.mark.parametrize('shape', CONV_SHAPES)
+def test_conv_dgrad(K, shape):
+    B, Cin, Cout, H, W, ks = shape
+    gy, w = rnd(B, Cout, H, W), rnd(Cout, Cin, ks, ks, scale=0.2)
+    run_both(K, 'conv2d_dgrad', [gy, w, torch.zeros(B, Cin, H, W), B, Cin, Cout, H, W, ks], [2], tol=2e-5)
+
+
+@pytest.mark.parametrize('shape', CONV_SHAPES)
+def test_conv_wgrad(K, shape):
+    B, Cin, Cout, H, W, ks = shape
+    x, gy = rnd(B, Cin, H, W), rnd(B, Cout, H, W, seed=3)
+    nbytes = K.conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks)
+    assert nbytes > 0
+    ws = torch.zeros(nbytes // 4 + 4)
+    run_both(K, 'conv2d_wgrad', [x, gy, torch.zeros(Cout, Cin, ks, ks), ws, ws.numel() * 4, B, Cin, Cout, H, W, ks],
+             [2], tol=5e-5)
+
+
+def test_conv_wgrad_is_deterministic(K):
+    B, Cin, Cout, H, W, ks = 4, 32, 32, 32, 32, 3
+    x, gy = rnd(B, Cin, H, W).cuda(), rnd(B, Cout, H, W, seed=3).cuda()
+    ws = torch.zeros(K.conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks) // 4 + 4).cuda()
+    outs = []
+    for _ in range(3):
+        gw = torch.zeros(Cout, Cin, ks, ks).cuda()
+        K.conv2d_wgrad(x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks)
+        outs.append(gw.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+def test_conv_rejects_unsupported(K):
+    x = torch.zeros(1, 4, 8, 8).cuda()
+    with pytest.raises(RuntimeError):
+        K.conv2d_fwd(x, torch.zeros(4, 4, 5, 5).cuda(), None, torch.zeros(1, 4, 8, 8).cuda(), 1, 4, 4, 8, 8, 5)
+
+
+BN_SHAPES = [(4, 16, 64 * 64), (8, 128, 16), (3, 3, 32 * 32), (2, 32, 128 * 128), (5, 100, 8 * 8), (64, 128, 1), (2, 7, 12 * 10)]
+
+
+@pytest.mark.parametrize('shape', BN_SHAPES)
+def test_batchnorm_all_passes(K, shape):
+    B, C, HW = shape
+    x = rnd(B, C, HW) * 1.5 + 0.3
+    gamma, beta = 1 + 0.1 * rnd(C), 0.1 * rnd(C, seed=1)
+    rm, rv = 0.05 * rnd(C, seed=2), 1 + 0.1 * torch.rand(C)
+    ws = torch.zeros(K.bn_workspace(B, C, HW) // 4 + 4)
+    mean, invstd = torch.zeros(C), torch.zeros(C)
+    run_both(K, 'bn_train_stats', [x, mean, invstd, rm, rv, 0.1, 1e-5, ws, B, C, HW], [1, 2, 3, 4], tol=1e-5)
+    E.bn_train_stats(x, mean, invstd, None, None, 0.1, 1e-5, None, B, C, HW)
+    run_both(K, 'bn_eval_stats', [rm, rv, torch.zeros(C), torch.zeros(C), 1e-5, C], [2, 3], tol=1e-6)
+    for slope in (0.2, 1.0):
+        run_both(K, 'bn_act_fwd', [x, mean, invstd, gamma, beta, slope, torch.zeros(B, C, HW), B, C, HW], [6], tol=1e-5)
+        gz = rnd(B, C, HW, seed=5)
+        for training in (1, 0):
+            run_both(K, 'bn_act_bwd', [gz, x, mean, invstd, gamma, beta, slope, training, torch.zeros(B, C, HW),
+                                       torch.zeros(C), torch.zeros(C), ws, B, C, HW], [8, 9, 10], tol=3e-5)
+        run_both(K, 'bn_act_bwd', [gz, x, mean, invstd, gamma, beta, slope, 1, None, torch.zeros(C), torch.zeros(C),
+                                   ws, B, C, HW], [9, 10], tol=3e-5)
+        v = rnd(B, C, HW, seed=6)
+        for vg, vb in ((rnd(C, seed=7), rnd(C, seed=8)), (None, None)):
+            run_both(K, 'bn_act_dbwd', [v, vg, vb, gz, x, mean, invstd, gamma, beta, slope, torch.zeros(B, C, HW),
+                                        torch.zeros(B, C, HW), torch.zeros(C), ws, B, C, HW], [10, 11, 12], tol=5e-5)
+
+
+@pytest.mark.parametrize('shape', [(6, 4, 4), (8, 16, 16), (3, 64, 64), (5, 10, 6)])
+def test_resample(K, shape):
+    BC, H, W = shape
+    x = rnd(BC, H, W)
+    for alpha in (1.0, 0.25):
+        run_both(K, 'up2x', [x, torch.zeros(BC, 2 * H, 2 * W), alpha, BC, H, W], [1], tol=1e-6)
+        run_both(K, 'pool2', [x, torch.zeros(BC, H // 2, W // 2), alpha, BC, H, W], [1], tol=1e-6)
+    run_both(K, 'bilinear_half_fwd', [x, torch.zeros(BC, H // 2, W // 2), BC, H, W], [1], tol=2e-6)
+    run_both(K, 'bilinear_half_bwd', [rnd(BC, H // 2, W // 2), torch.zeros(BC, H, W), BC, H, W], [1], tol=2e-6)
+    idx = torch.zeros(BC, H // 2, W // 2, dtype=torch.uint8)
+    run_both(K, 'maxpool2_fwd', [x, torch.zeros(BC, H // 2, W // 2), idx, BC, H, W], [1, 2], atol=0.0)
+    E.maxpool2_fwd(x, torch.zeros(BC, H // 2, W // 2), idx, BC, H, W)
+    run_both(K, 'maxpool2_bwd', [rnd(BC, H // 2, W // 2), idx, torch.zeros(BC, H, W), BC, H, W], [2], atol=0.0)
+    run_both(K, 'maxpool2_gather', [x, idx, torch.zeros(BC, H // 2, W // 2), BC, H, W], [2], atol=0.0)
+
+
+def test_maxpool_ties_pick_first(K):
+    x = torch.ones(2, 4, 4)
+    idx = torch.zeros(2, 2, 2, dtype=torch.uint8)
+    run_both(K, 'maxpool2_fwd', [x, torch.zeros(2, 2, 2), idx, 2, 4, 4], [1, 2], atol=0.0)
+
+
+GEMM_CASES = [
+    # M, N, K, ta, tb, batch
+    (64, 2048, 256, 0, 1, 1), (64, 1, 128, 0, 1, 1), (512, 128, 20, 0, 1, 1), (256, 64, 16, 1, 0, 3),
+    (16, 256, 64, 0, 1, 3), (4096, 1024, 4, 1, 0, 2), (100, 37, 19, 1, 1, 2), (33, 65, 17, 0, 0, 1),
+]
+
+
+@pytest.mark.parametrize('case', GEMM_CASES)
+def test_gemm(K, case):
+    M, N, Kd, ta, tb, batch = case
+    A = rnd(batch, Kd, M) if ta else rnd(batch, M, Kd)
+    Bm = rnd(batch, N, Kd, seed=1) if tb else rnd(batch, Kd, N, seed=1)
+    lda, ldb = A.shape[-1], Bm.shape[-1]
+    for bias in (None, rnd(N, seed=2)):
+        run_both(K, 'gemm', [A, Bm, torch.zeros(batch, M, N), bias, M, N, Kd, lda, ldb, N, ta, tb, batch,
+                             A[0].numel(), Bm[0].numel(), M * N], [2], tol=2e-5)
+
+
+def test_row_and_channel_ops(K):
+    B, C, HW = 5, 12, 48
+    x = rnd(B, C, HW)
+    ws = torch.zeros(K.bn_workspace(B, C, HW) // 4 + 4)
+    run_both(K, 'channel_sum', [x, torch.zeros(C), ws, B, C, HW], [1], tol=1e-5)
+    xb = rnd(3, 16, 64 * 64)
+    wsb = torch.zeros(K.bn_workspace(3, 16, 64 * 64) // 4 + 4)
+    run_both(K, 'channel_sum', [xb, torch.zeros(16), wsb, 3, 16, 64 * 64], [1], tol=1e-5)
+    run_both(K, 'channel_bcast', [rnd(C), torch.zeros(B, C, HW), B, C, HW], [1], atol=0.0)
+    run_both(K, 'channel_bcast', [rnd(16), torch.zeros(3, 16, 64 * 64), 3, 16, 64 * 64], [1], atol=0.0)
+    run_both(K, 'row_sum', [x, torch.zeros(B * C), 1.0, B * C, HW], [1], tol=1e-5)
+    run_both(K, 'row_sum', [rnd(1, 300), torch.zeros(1), 0.5, 1, 300], [1], tol=1e-5)
+    run_both(K, 'row_bcast', [rnd(B * C), torch.zeros(B * C, HW), 0.5, B * C, HW], [1], tol=1e-6)
+    run_both(K, 'repeat_rows', [rnd(7, 9), torch.zeros(8 * 7, 9), 1.0, 7, 9, 8], [1], atol=0.0)
+    run_both(K, 'sum_reps', [rnd(8 * 7, 9), torch.zeros(7, 9), 0.125, 7, 9, 8], [1], tol=1e-6)
+
+
+def test_elementwise(K):
+    for n in (1, 5, 1024, 4099):
+        a, b = rnd(n), rnd(n, seed=1)
+        run_both(K, 'add', [a, b, torch.zeros(n), n], [2], atol=0.0)
+        run_both(K, 'mul', [a, b, torch.zeros(n), n], [2], atol=0.0)
+        run_both(K, 'scale', [a, 0.3, torch.zeros(n), n], [2], tol=1e-7)
+        s = torch.tensor(1.7)
+        run_both(K, 'scale_dev', [s, 0.5, a, torch.zeros(n), n], [3], tol=1e-6)
+        run_both(K, 'scale_add_dev', [s, a, b, torch.zeros(n), n], [3], tol=1e-6)
+        ws = torch.zeros(K.reduce_workspace(n) // 4 + 4)
+        run_both(K, 'dot', [a, b, 0.5, torch.zeros(()), ws, n], [3], tol=1e-5, atol=1e-5 * n ** 0.5)
+        run_both(K, 'sumsq', [a, 0.25, torch.zeros(()), ws, n], [2], tol=1e-5)
+        run_both(K, 'lrelu_bwd', [a, b, 0.2, torch.zeros(n), n], [3], atol=0.0)
+        y = torch.tanh(a)
+        run_both(K, 'tanh_fwd', [a, torch.zeros(n), n], [1], tol=1e-6)
+        run_both(K, 'tanh_bwd', [b, y, torch.zeros(n), n], [2], tol=1e-6)
+        run_both(K, 'fill', [torch.ones(n), 2.5, n], [0], atol=0.0)
+
+
+def test_unaligned_views(K):
+    base = rnd(1030).cuda()
+    a, b = base[1:1025], base[3:1027]
+    out = torch.zeros(1030).cuda()
+    K.add(a, b, out[5:1029], 1024)
+    assert torch.allclose(out[5:1029].cpu(), (a + b).cpu())
+
+
+@pytest.mark.parametrize('shape', [(7, 16), (64, 64), (33, 1024), (5, 300)])
+def test_softmax(K, shape):
+    rows, cols = shape
+    s = rnd(rows, cols) * 3
+    y = torch.softmax(s, -1)
+    run_both(K, 'softmax_fwd', [s, torch.zeros(rows, cols), rows, cols], [1], tol=2e-6)
+    gy, v = rnd(rows, cols, seed=1), rnd(rows, cols, seed=2)
+    run_both(K, 'softmax_bwd', [gy, y, torch.zeros(rows, cols), rows, cols], [2], tol=1e-5)
+    run_both(K, 'softmax_dbwd', [v, gy, y, torch.zeros(rows, cols), rows, cols], [3], tol=1e-5)
+
+
+def test_iqn_and_losses(K):
+    Q, B = 8, 24
+    taus = torch.rand(Q * B, 1)
+    rng = torch.arange(1, 21).float()
+    run_both(K, 'iqn_cos_embed', [taus, rng, torch.zeros(Q * B, 20), Q * B, 20], [2], atol=2e-5)
+    preds = rnd(Q * B, 1) * 2
+    preds[3] = 1.0                       # err == 0 for a target of 1: indicator and Huber branch edge
+    preds[5] = 3.0                       # |err| = 2 > k: linear branch
+    target = (torch.arange(B) % 2).float().view(B, 1)
+    ws = torch.zeros(K.reduce_workspace(Q * B) // 4 + 4)
+    run_both(K, 'iqn_loss', [preds, target, taus, 1.0, torch.zeros(()), torch.zeros(Q * B, 1), ws, Q, B], [4, 5], tol=2e-6)
+    logits, t = rnd(48, 1) * 4, (torch.arange(48) % 2).float().view(48, 1)
+    run_both(K, 'bce_logits', [logits, t, torch.zeros(()), torch.zeros(48, 1), ws, 48], [2, 3], tol=2e-6)
+
+
+def test_adam_and_ema(K):
+    n = 5000
+    p, g, m, v = rnd(n), rnd(n, seed=1) * 1e-2, torch.zeros(n), torch.zeros(n)
+    g[:10] = 0.0
+    for step in (1, 2, 7):
+        b1, b2 = 0.0, 0.999
+        hyper = torch.tensor([4e-4 / (1 - b1 ** step), (1 - b2 ** step) ** 0.5, b1, b2, 1 - b1, 1 - b2])
+        run_both(K, 'adam_step', [p, g, m, v, hyper, 1e-8, n], [0, 2, 3], tol=1e-6)
+        E.adam_step(p, g, m, v, hyper, 1e-8, n)
+    hyper = torch.tensor([1e-3 / (1 - 0.9 ** 3), (1 - 0.999 ** 3) ** 0.5, 0.9, 0.999, 1 - 0.9, 1 - 0.999])
+    run_both(K, 'adam_step', [p, g, rnd(n, seed=4) * 1e-2, v, hyper, 1e-8, n], [0, 2, 3], tol=1e-6)
+    run_both(K, 'ema', [rnd(n, seed=2), p, 1e-3, n], [0], tol=1e-7)
