@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark: images/sec of the full SA-GAN G+D training step (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): GAN_CONFIGS['128'] with the author's attention placement (3,)
+("128:3"), tartangan.trainers.cnn step semantics (BCE + R1 penalty 5.0, Adam(0,.999) x2, EMA),
+fp32, 128x128 RGB, batch 64 PER GPU (weak scaling), synthetic U[-1,1] images resident in HBM,
+random-init weights.  One "step" = one train_batch(): D phase incl. second-order R1 backward,
+D Adam, G phase, G Adam, EMA, and the reference's loss read-back (one host sync per step).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel family (the MFMA
+implicit-GEMM convolution, fwd+dgrad), timed with HIP events on the launch stream in an
+instrumented eager pass of the same step right after the timed region; `roofline_step` is
+the whole step against the fp32 MFMA floor.  `cpu_baseline` is the CPU oracle
+(oracle/sagan_cpu.py, kind "port") timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_IMAGE = {'128:3': 1.0446e10, '128': 9.5473e9, '64:1': 7.3881e9, '64': 7.3044e9, '32': 1.6857e9}
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32 / 16x16x4_f32
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--config', default='128:3')
+    p.add_argument('--trainer', default='cnn', choices=['cnn', 'iqn'])
+    p.add_argument('--batch', type=int, default=64, help='per-GPU batch')
+    p.add_argument('--eager', action='store_true', help='do not replay HIP graphs')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-kernel-timing', action='store_true')
+    p.add_argument('--cpu-batch', type=int, default=16)
+    return p.parse_args()
+
+
+def make_trainer(config, kind, batch, device):
+    from tartangan_amd.models.pluggan import GAN_CONFIGS
+    from tartangan_amd.trainers.cnn import CNNTrainer
+    from tartangan_amd.trainers.iqn import IQNTrainer
+    name, _, att = config.partition(':')
+    cfg = GAN_CONFIGS[name]
+    if att:
+        cfg = cfg._replace(attention=(int(att),))
+    cls = {'cnn': CNNTrainer, 'iqn': IQNTrainer}[kind]
+    tr = cls(cls.default_args(config=cfg, batch_size=batch, device=device))
+    torch.manual_seed(1234)
+    tr.build_models()
+    return tr, cfg
+
+
+class KernelTimer:
+    """HIP-event timing of every C-ABI launch of one eager step, on the launch stream."""
+
+    def __init__(self, backend):
+        self.K = backend
+        self.records = []
+        self._saved = {}
+
+    def __enter__(self):
+        for name in ('conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad', 'bn_train_stats', 'bn_act_fwd', 'bn_act_bwd',
+                     'bn_act_dbwd', 'gemm', 'softmax_fwd', 'softmax_bwd', 'softmax_dbwd', 'up2x', 'pool2',
+                     'bilinear_half_fwd', 'bilinear_half_bwd', 'add', 'channel_sum', 'adam_step', 'ema'):
+            fn = getattr(self.K, name)
+            self._saved[name] = fn
+            setattr(self.K, name, self._wrap(name, fn))
+        return self
+
+    def _wrap(self, name, fn):
+        def timed(*args):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn(*args)
+            b.record()
+            self.records.append((name, args, a, b))
+            return rc
+        return timed
+
+    def __exit__(self, *exc):
+        for name, fn in self._saved.items():
+            setattr(self.K, name, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, args, a, b in self.records:
+            ms = a.elapsed_time(b)
+            flops = 0.0
+            if name in ('conv2d_fwd', 'conv2d_dgrad'):
+                B, Cin, Cout, H, W, ks = args[-6:]
+                flops = 2.0 * B * Cin * Cout * H * W * ks * ks
+            elif name == 'conv2d_wgrad':
+                B, Cin, Cout, H, W, ks = args[-6:]
+                flops = 2.0 * B * Cin * Cout * H * W * ks * ks
+            d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0))
+            d['ms'] += ms
+            d['launches'] += 1
+            d['flops'] += flops
+        return agg
+
+
+def cpu_baseline(config, kind, batch):
+    from oracle import sagan_cpu as O
+    name, _, att = config.partition(':')
+    torch.manual_seed(1234)
+    tr = O.OracleTrainer(name, kind, batch, attention=(int(att),) if att else None)
+    size = tr.cfg.base_size * 2 ** len(tr.cfg.blocks)
+    imgs = torch.rand(batch, 3, size, size) * 2 - 1
+    tr.train_batch(imgs)                       # untimed first step (allocator / thread-pool warm-up)
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        tr.train_batch(imgs)
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} timed steps (+1 untimed) of the {config} {kind} step at batch {batch} on the host CPU, '
+                       f'oracle/sagan_cpu.py (plain PyTorch CPU fp32)')
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from tartangan_amd import backend
+    K = backend.get()                          # fails loudly without the HIP library
+    tr, cfg = make_trainer(a.config, a.trainer, a.batch, 'cuda')
+    if world > 1:
+        from tartangan_amd.parallel import DataParallel
+        if not a.eager:
+            tr.enable_graphs()
+        DataParallel(tr)
+    elif not a.eager:
+        tr.enable_graphs()
+    size = tr.g.max_size
+    g = torch.Generator().manual_seed(1234)
+    imgs_global = torch.rand(a.batch * world, 3, size, size, generator=g) * 2 - 1
+    imgs = imgs_global[rank * a.batch:(rank + 1) * a.batch].cuda()     # resident in HBM before timing
+    torch.manual_seed(1234)
+
+    warm = max(a.warmup, 0 if a.eager else 2)  # graph mode: step 1 eager (records RNG plan), step 2 captures
+    for _ in range(warm):
+        logs = tr.train_batch(imgs)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        logs = tr.train_batch(imgs)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / a.steps * 1e3
+    value = a.batch * world * a.steps / dt
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec (G+D step)', 'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world,
+            'steps': a.steps, 'warmup': warm, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{a.config} SA-GAN {a.trainer} G+D step (R1 penalty, Adam x2, EMA), '
+                                   f'{size}x{size} RGB, batch {a.batch}/GPU, global batch {a.batch * world}',
+                       'trainer': a.trainer, 'gan_config': a.config, 'global_batch': a.batch * world,
+                       'parallelism': f'dp{world}' + ('' if world == 1 else ' (local-batch BatchNorm, flat-bucket RCCL all-reduce x2)'),
+                       'hip_graphs': not a.eager},
+            'final_losses': {k: round(v, 6) for k, v in logs.items()},
+        }
+        flop_img = FLOP_PER_IMAGE.get(a.config)
+        if flop_img and a.trainer == 'cnn':
+            tf = flop_img * value / world / 1e12
+            out['roofline_step'] = {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': MFMA_F32_PEAK_TFLOPS,
+                                    'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                                    'flop_per_image': flop_img}
+        if not a.no_kernel_timing:
+            # instrumented eager pass of the same step (same kernels, same shapes) with HIP events
+            saved = (getattr(tr, '_graphs', None), getattr(tr, '_graph_requested', False), tr.rng_feed.mode)
+            tr._graphs, tr._graph_requested = None, False
+            tr.rng_feed.mode = 'off'
+            with KernelTimer(K) as kt:
+                tr.train_batch(imgs) if world == 1 else None
+            agg = kt.summary() if world == 1 else {}
+            tr._graphs, tr._graph_requested, tr.rng_feed.mode = saved
+            if agg:
+                conv = {'ms': agg['conv2d_fwd']['ms'] + agg['conv2d_dgrad']['ms'],
+                        'launches': agg['conv2d_fwd']['launches'] + agg['conv2d_dgrad']['launches'],
+                        'flops': agg['conv2d_fwd']['flops'] + agg['conv2d_dgrad']['flops']}
+                ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
+                out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (MFMA implicit-GEMM conv, fwd + dgrad launches)',
+                                   'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                                   'launches_per_step': conv['launches'],
+                                   'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
+                                   'algorithmic_flop_per_step': conv['flops']}
+                total = sum(d['ms'] for d in agg.values())
+                out['kernel_time_ms'] = {k: {'ms': round(d['ms'], 4), 'launches': d['launches'],
+                                             **({'tflops': round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2)} if d['flops'] else {})}
+                                         for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
+                out['kernel_time_ms']['_sum_of_timed_launches'] = round(total, 4)
+        if not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a.config, a.trainer, a.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -33,6 +33,7 @@ class IQN(nn.Module):
         self.num_quantiles = num_quantiles
         self.mix = mix
         self._device = None
+        self.tau_source = None      # optional callable(rows, num_quantiles) -> (rows, 1) device tensor
 
     def forward(self, x):
         batch_size = x.shape[0]
@@ -46,6 +47,8 @@ class IQN(nn.Module):
         raise ValueError(f'Unknown mix method {self.mix}')
 
     def sample_quantiles(self, n=1):
+        if self.tau_source is not None:
+            return self.tau_source(n * self.num_quantiles, self.num_quantiles)
         if self._device is None:
             self._device = next(self.parameters()).device
         return torch.rand(n * self.num_quantiles, 1).to(self._device)

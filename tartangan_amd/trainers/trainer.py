@@ -15,6 +15,60 @@ import torch
 from .utils import set_device_from_args
 
 
+class RngFeed:
+    """Host-side random inputs of one step (latents z, IQN quantile fractions tau).
+
+    The reference draws them from the CPU default generator inside the step and moves them
+    to the device (trainer.py:153-156, models/iqn.py:105-108).  To replay the step from
+    captured HIP graphs the draws have to happen before the launch, into static device
+    buffers, in exactly the reference's order.  The first (eager) step records that order;
+    afterwards ``refill`` reproduces it.  Under data parallelism every rank draws the GLOBAL
+    tensor from the same seed and keeps its own rows (tau rows are quantile-major:
+    row = q * B + b), so the union over ranks is the single-process stream.
+    """
+
+    def __init__(self, device, rank=0, world=1):
+        self.device, self.rank, self.world = device, rank, world
+        self.plan = []          # [(kind, local_rows, cols)]
+        self.static = []
+        self.host = []
+        self.mode = 'record'
+        self.cursor = 0
+
+    def _draw_cpu(self, kind, rows, cols):
+        if kind == 'z':
+            full = torch.randn(rows * self.world, cols)
+            return full[self.rank * rows:(self.rank + 1) * rows]
+        # tau: (Q*B_global, 1) with row = q*B_global + b  ->  this rank's (Q*B, 1)
+        q = cols
+        full = torch.rand(rows * self.world, 1)
+        b_local = rows // q
+        return full.view(q, b_local * self.world)[:, self.rank * b_local:(self.rank + 1) * b_local].reshape(rows, 1)
+
+    def draw(self, kind, rows, cols):
+        """kind 'z': (rows, cols) normal;  kind 'tau': (rows, 1) uniform with cols = num_quantiles."""
+        if self.mode == 'off':
+            return self._draw_cpu(kind, rows, cols).contiguous().to(self.device)
+        if self.mode == 'record':
+            val = self._draw_cpu(kind, rows, cols).contiguous()
+            buf = val.to(self.device)
+            self.plan.append((kind, rows, cols))
+            self.static.append(buf)
+            host = torch.empty_like(val)
+            self.host.append(host.pin_memory() if buf.is_cuda else host)
+            return buf
+        buf = self.static[self.cursor]          # 'serve'
+        assert self.plan[self.cursor] == (kind, rows, cols), 'step structure changed since it was recorded'
+        self.cursor += 1
+        return buf
+
+    def refill(self):
+        for (kind, rows, cols), buf, host in zip(self.plan, self.static, self.host):
+            host.copy_(self._draw_cpu(kind, rows, cols))
+            buf.copy_(host, non_blocking=True)
+        self.cursor = 0
+
+
 class Trainer:
     def __init__(self, args, components=()):
         self.args = args
@@ -23,6 +77,9 @@ class Trainer:
         self.components = list(components)
         self.steps = 0
         self.epoch = 1
+        self.data_parallel = None
+        self.rng_feed = RngFeed(self.device)
+        self.rng_feed.mode = 'off'
 
     # ------------------------------------------------------------------ hot-path helpers
     @property
@@ -34,7 +91,7 @@ class Trainer:
         a seed gives the same z on any device."""
         if n is None:
             n = self.args.batch_size
-        return torch.randn(n, self.gan_config.latent_dims).to(self.device)
+        return self.rng_feed.draw('z', n, self.gan_config.latent_dims)
 
     def sample_g(self, n=None, target_g=False, **g_kwargs):
         z = self.sample_z(n)

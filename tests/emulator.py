@@ -287,9 +287,9 @@ class Emulator:
 
     # ---------------------------------------------------------------- optimiser
     def adam_step(self, p, g, m, v, hyper, eps, n):
-        step_size, bc2_sqrt, b1, b2 = [float(h) for h in hyper[:4]]
-        m.lerp_(g, 1 - b1)
-        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        step_size, bc2_sqrt, b1, b2, omb1, omb2 = [float(h) for h in hyper]
+        m.lerp_(g, omb1)
+        v.mul_(b2).addcmul_(g, g, value=omb2)
         denom = (v.sqrt() / bc2_sqrt).add_(eps)
         p.addcdiv_(m, denom, value=-step_size)
         return 0

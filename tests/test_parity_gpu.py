@@ -62,23 +62,57 @@ def test_hip_trainer_matches_reference_fixture(case):
     for k, ref in enumerate(fx['steps']):
         logs = tr.train_batch(synthetic_images(fx['batch'], fx['size'], fx['img_seed'] + k))
         loss_tol, grad_tol = (1e-4, 2e-3) if k == 0 else (1e-1, 1.0)
+        # the G phase runs after D's first Adam step, which moves every weight by ~lr*sign(grad): weights whose
+        # true gradient is ~0 get a rounding-determined sign, so G-side gradients are only bounded loosely here
+        # (they are pinned tightly, from identical D state, in test_g_phase_gradients_match_oracle)
+        g_grad_tol = 2e-2 if k == 0 else 1.0
         for name in ('g_loss', 'd_loss', 'gp'):
             assert _close(logs[name], ref[name], loss_tol), (case, k, name, logs[name], ref[name])
         assert _close(_total_l2(tr.g), ref['g_l2'], 1e-4)
         assert _close(_total_l2(tr.d), ref['d_l2'], 1e-4)
         assert _close(_total_l2(tr.target_g), ref['target_g_l2'], 1e-4)
-        assert _close(_total_l2(tr.g, True), ref['g_grad_l2'], grad_tol), (case, k)
+        assert _close(_total_l2(tr.g, True), ref['g_grad_l2'], g_grad_tol), (case, k)
         assert _close(_total_l2(tr.d, True), ref['d_grad_l2'], grad_tol), (case, k)
         if k == 0:
             for name, p in tr.d.named_parameters():
                 ref_s = fx['after_step1']['d_grad'][name]
                 got = summarize(p.grad, len(ref_s['idx']))
                 assert _close(got['l2'], ref_s['l2'], 2e-3, 5e-5 * ref['d_grad_l2']), ('d_grad', name, got['l2'], ref_s['l2'])
-            for name, p in tr.g.named_parameters():
-                ref_s = fx['after_step1']['g_grad'][name]
-                got = summarize(p.grad, len(ref_s['idx']))
-                assert _close(got['l2'], ref_s['l2'], 5e-3, 1e-4 * ref['g_grad_l2']), ('g_grad', name, got['l2'], ref_s['l2'])
     assert float(torch.rand(1)) == fx['rng_after']          # z / tau RNG stream consumed like the reference
+
+
+@pytest.mark.parametrize('case', ['c32_cnn_b16', 'c32a2_iqn_b8', 'c64a1_cnn_b8', 'c128a3_iqn_b4'])
+def test_g_phase_gradients_match_oracle(case):
+    """G-phase gradients (first-order backward through D and G) from identical, un-stepped state:
+    HIP vs the CPU oracle, per parameter tensor."""
+    from oracle import sagan_cpu as O
+    fx = load_golden(case)
+    tr = make_trainer(fx)
+    torch.manual_seed(0)
+    ref = O.OracleTrainer(fx['config'], fx['trainer'], fx['batch'], attention=fx['attention'])
+    gs, ds = procedural_state(ref.g, fx['weight_seed']), procedural_state(ref.d, fx['weight_seed'] + 2)
+    ref.load(g=gs, d=ds)
+    tr.g.load_state_dict(gs)
+    tr.d.load_state_dict(ds)
+    tr.g.train(); tr.d.train()
+    torch.manual_seed(77)
+    g_loss = float(tr._g_phase(fx['batch']))
+    # oracle G phase (trainers/cnn.py:139-148) with the same RNG stream
+    torch.manual_seed(77)
+    ref._toggle(ref.g, True); ref._toggle(ref.d, False)
+    fake = O.g_forward(ref.g, ref.sample_z(fx['batch']), ref.cfg)
+    ones = torch.ones(fx['batch'], 1)
+    if fx['trainer'] == 'iqn':
+        _, want = ref._d(fake, ones)
+    else:
+        want = torch.nn.functional.binary_cross_entropy_with_logits(ref._d(fake), ones)
+    want.backward()
+    assert _close(g_loss, float(want), 2e-5)
+    total = sum(float(v.grad.double().pow(2).sum()) for k, v in ref.g.items() if O.is_param(k)) ** 0.5
+    for name, p in tr.g.named_parameters():
+        w = ref.g[name].grad
+        err = float((p.grad.cpu() - w).abs().max())
+        assert err <= 1e-3 * float(w.abs().max()) + 1e-5 * total, (name, err, float(w.abs().max()))
 
 
 def test_forward_pins_and_iqn_tau_exactness():
@@ -110,6 +144,34 @@ def test_forward_pins_and_iqn_tau_exactness():
         ref = fx['forward']['g_out_eval']
         got = summarize(g2(z.cuda()), len(ref['idx']))
         assert _close(got['l2'], ref['l2'], 1e-5)
+
+
+@pytest.mark.parametrize('case', ['c32a2_cnn_b8', 'c32a2_iqn_b8'])
+def test_graph_replay_equals_eager(case):
+    """The three captured HIP graphs replay exactly the eager step (same kernels, same RNG stream)."""
+    fx = load_golden(case)
+    runs = []
+    for graphed in (False, True):
+        tr = make_trainer(fx)
+        tr.g.load_state_dict(procedural_state(tr.g.state_dict(), fx['weight_seed']))
+        tr.target_g.load_state_dict(procedural_state(tr.target_g.state_dict(), fx['weight_seed'] + 1))
+        tr.d.load_state_dict(procedural_state(tr.d.state_dict(), fx['weight_seed'] + 2))
+        if graphed:
+            tr.enable_graphs()
+        torch.manual_seed(fx['rng_seed'])
+        logs = [tr.train_batch(synthetic_images(fx['batch'], fx['size'], fx['img_seed'] + k).cuda()) for k in range(4)]
+        runs.append((logs, tr.optimizer_g.flat.clone(), tr.optimizer_d.flat.clone(), tr.d.state_dict(), float(torch.rand(1))))
+    (le, ge, de, sde, re_), (lg, gg, dg, sdg, rg) = runs
+    assert re_ == rg
+    for a, b in zip(le, lg):
+        for k in a:
+            assert _close(a[k], b[k], 1e-6), (k, a[k], b[k])
+    assert torch.allclose(ge, gg, rtol=0, atol=1e-6) and torch.allclose(de, dg, rtol=0, atol=1e-6)
+    for k in sde:
+        assert torch.allclose(sde[k].float(), sdg[k].float(), rtol=1e-5, atol=1e-6), k
+    # first step of the fixture still matches the reference through the graphed path
+    for name in ('g_loss', 'd_loss', 'gp'):
+        assert _close(lg[0][name], fx['steps'][0][name], 1e-4)
 
 
 def test_native_library_is_loaded():
