@@ -68,13 +68,18 @@ __global__ void __launch_bounds__(RS_BLOCK) pool2_scalar(const float* __restrict
 // ATen's source-index computation in fp32 (UpSample.h area_pixel_compute_source_index, align_corners)
 struct Lerp { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Lerp src_index(int o, float scale, int in_size) {
-  const float r = scale * (float)o;
+  // ATen rounds scale*o to fp32 BEFORE taking the fractional part; an fma(scale, o, -i0) here changes
+  // lambda by up to ulp(r) (7.6e-6 at 128 px), which was measurable end to end (gp off by 7e-5).
+  // hipcc contracts through __fmul_rn and `#pragma clang fp contract(off)` alike (checked in the ISA:
+  // v_pk_fma_f32 scale, o, -i0); the empty asm makes the rounded product opaque, which does stop it.
+  float r = scale * (float)o;
+  asm volatile("" : "+v"(r));
   Lerp t;
   t.i0 = (int)r;
   if (t.i0 > in_size - 1) t.i0 = in_size - 1;
   t.i1 = t.i0 + ((t.i0 < in_size - 1) ? 1 : 0);
-  t.l1 = r - (float)t.i0;
-  t.l0 = 1.f - t.l1;
+  t.l1 = __fsub_rn(r, (float)t.i0);
+  t.l0 = __fsub_rn(1.f, t.l1);
   return t;
 }
 
