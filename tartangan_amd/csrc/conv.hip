@@ -27,13 +27,18 @@ constexpr int CT_THREADS = 256;
 
 template <int TH_, int TW_, int NI_>
 struct Geo {
-  static constexpr int TH = TH_, TW = TW_, NI = NI_;
-  static_assert(TH_ * TW_ * NI_ == 256, "a pixel tile is 256 pixels");
+  static constexpr int TH = TH_, TW = TW_, NI = NI_, NPIX = TH_ * TW_ * NI_;
+  static_assert(NPIX == 256 || NPIX == 64, "a pixel tile is 256 pixels (waves split pixels) or 64 (waves split K)");
 };
 using G4 = Geo<4, 4, 16>;
 using G8 = Geo<8, 8, 4>;
 using G16 = Geo<16, 16, 1>;
 using GX = Geo<8, 32, 1>;
+// 64-pixel tiles for the small-spatial layers: the 4 waves share the pixels and split the K dimension,
+// so an 8x8 / 16x16 layer still spreads over >= 256 workgroups
+using G4k = Geo<4, 4, 4>;
+using G8k = Geo<8, 8, 1>;
+using G16k = Geo<4, 16, 1>;
 
 template <class G, int KS>
 struct Patch {
@@ -104,20 +109,20 @@ __device__ __forceinline__ void stage_patch(const float* __restrict__ x, float* 
 
 // =========================================================================== forward / dgrad
 // CK input channels per chunk; filter slice in LDS as wl[(ci*KK + tap)][co] with row stride CTS.
-template <int KS> struct FwdCfg { static constexpr int CK = (KS == 3) ? 8 : 32; };
+template <int KS, bool WK> struct FwdCfg { static constexpr int CK = (KS == 3) ? (WK ? 16 : 8) : 32; };
 
-template <int KS, int CT>
+template <int KS, int CT, bool WK>
 struct WTile {
   static constexpr int KK = KS * KS;
-  static constexpr int CK = FwdCfg<KS>::CK;
+  static constexpr int CK = FwdCfg<KS, WK>::CK;
   static constexpr int CTS = (CT % 32 == 16) ? CT : CT + 16;   // row stride % 32 == 16: two k-rows of a 32-lane group on disjoint banks
   static constexpr int SIZE = CK * KK * CTS;
 };
 
-template <int KS, int CT, bool DGRAD>
+template <int KS, int CT, bool DGRAD, bool WK>
 __device__ __forceinline__ void stage_weights(const float* __restrict__ w, float* __restrict__ wl, int Cin, int Cout, int ci0,
                                               int co0) {
-  using WT = WTile<KS, CT>;
+  using WT = WTile<KS, CT, WK>;
   constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS;
   constexpr int TOTAL = CT * CK * KK;
   for (int e = threadIdx.x; e < TOTAL; e += CT_THREADS) {
@@ -151,12 +156,19 @@ __global__ void __launch_bounds__(CT_THREADS)
 conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
                 Shape s) {
   using P = Patch<G, KS>;
+  constexpr bool WK = (G::NPIX == 64);        // waves split K (same pixels) instead of pixels
   constexpr int CT = MF * MT;
-  using WT = WTile<KS, CT>;
+  using WT = WTile<KS, CT, WK>;
   constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS;
   constexpr int NT = 64 / MF;                 // pixel sub-tiles per wave (64 pixels per wave)
   constexpr int KG = (MF == 32) ? 2 : 4;      // k values consumed per MFMA
-  __shared__ float lds[CK * P::CIS + WT::SIZE];
+  constexpr int NREG = (MF == 32) ? 16 : 4;
+  constexpr int NG = CK / KG;                 // k-groups per chunk
+  constexpr int GSTEP = WK ? 4 : 1;           // WK: wave w takes k-groups w, w+4, ...
+  static_assert(!WK || NG % 4 == 0, "K-split needs a multiple of 4 k-groups per chunk");
+  constexpr int STAGE = CK * P::CIS + WT::SIZE;
+  constexpr int REDF = WK ? 4 * MT * NT * NREG * 64 : 0;
+  __shared__ float lds[STAGE > REDF ? STAGE : REDF];
   float* pl = lds;
   float* wl = lds + CK * P::CIS;
 
@@ -164,11 +176,13 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
   const int j = lane % MF, h = lane / MF;     // MF=32: h in {0,1}; MF=16: h in {0..3}
   const TileCoord tc = decode_tile<G>(blockIdx.x, s.H, s.W);
   const int co0 = blockIdx.y * CT;
+  const int pix0 = WK ? 0 : wave * 64;
+  const int g0 = WK ? wave : 0;
 
   int lane_b[NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) lane_b[n] = h * P::CIS + pix_off<G, KS>(wave * 64 + n * MF + j);
-  const int lane_a = (h * KK) * CTS + j;
+  for (int n = 0; n < NT; ++n) lane_b[n] = (h + g0 * KG) * P::CIS + pix_off<G, KS>(pix0 + n * MF + j);
+  const int lane_a = ((h + g0 * KG) * KK) * CTS + j;
 
   using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
   acc_t acc[MT][NT];
@@ -177,18 +191,19 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int r = 0; r < (MF == 32 ? 16 : 4); ++r) acc[m][n][r] = 0.f;
+      for (int r = 0; r < NREG; ++r) acc[m][n][r] = 0.f;
 
   for (int ci0 = 0; ci0 < s.Cin; ci0 += CK) {
     __syncthreads();
     stage_patch<G, KS, CK>(x, pl, s, s.Cin, ci0, tc);
-    stage_weights<KS, CT, DGRAD>(w, wl, s.Cin, s.Cout, ci0, co0);
+    stage_weights<KS, CT, DGRAD, WK>(w, wl, s.Cin, s.Cout, ci0, co0);
     __syncthreads();
     // skip all-zero k-groups of a ragged last chunk (wave-uniform)
     const int kgroups = (min(CK, s.Cin - ci0) + KG - 1) / KG;
 #pragma unroll
-    for (int g = 0; g < CK / KG; ++g) {
-      if (g < kgroups) {
+    for (int gi = 0; gi < NG / GSTEP; ++gi) {
+      const int g = gi * GSTEP;               // + g0 (in the lane bases)
+      if (g + g0 < kgroups) {
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
           const int kh = tap / KS, kw = tap % KS;
@@ -211,10 +226,34 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
     }
   }
 
-  // epilogue: D[row = co][col = pixel]
+  if constexpr (WK) {
+    // sum the four waves' partial accumulators through LDS (fixed order); wave w keeps registers
+    // [w*NREG/4, (w+1)*NREG/4) of every (m, n) tile for the store below
+    __syncthreads();
+    float* red = lds;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) red[(((wave * MT + m) * NT + n) * NREG + r) * 64 + lane] = acc[m][n][r];
+    __syncthreads();
+    constexpr int PW_ = MT * NT * NREG * 64;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          const int e = ((m * NT + n) * NREG + r) * 64 + lane;
+          acc[m][n][r] = (red[e] + red[PW_ + e]) + (red[2 * PW_ + e] + red[3 * PW_ + e]);
+        }
+  }
+
+  // epilogue: D[row = co][col = pixel]   (WK: each wave stores a quarter of the registers)
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int p = wave * 64 + n * MF + j;
+    const int p = pix0 + n * MF + j;
     const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
     const int b = tc.b0 + img, hh = tc.h0 + rem / G::TW, ww = tc.w0 + rem % G::TW;
     if (b >= s.B || hh >= s.H || ww >= s.W) continue;
@@ -223,7 +262,8 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
-      for (int r = 0; r < (MF == 32 ? 16 : 4); ++r) {
+      for (int r = 0; r < NREG; ++r) {
+        if (WK && (r / (NREG / 4)) != wave) continue;
         const int row = (MF == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * h) : (h * 4 + r);
         const int co = co0 + m * MF + row;
         if (co < s.Cout) y[base + co * cstride] = acc[m][n][r] + (bias ? bias[co] : 0.f);
@@ -332,12 +372,26 @@ conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, flo
   }
 }
 
+// gw[e] = sum_s part[s][e], fixed order.  64 consecutive e per workgroup (coalesced), the S partials
+// are split over the 4 waves and combined through LDS: no serial chain of S dependent loads.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int64_t E, int S) {
-  for (int64_t e = blockIdx.x * 256ll + threadIdx.x; e < E; e += gridDim.x * 256ll) {
-    float acc = 0.f;
-    for (int sidx = 0; sidx < S; ++sidx) acc += part[sidx * E + e];
-    gw[e] = acc;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t e = blockIdx.x * 64ll + lane;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < E) {
+    int sidx = wave;
+    for (; sidx + 12 < S; sidx += 16) {
+      a0 += part[(int64_t)sidx * E + e];
+      a1 += part[(int64_t)(sidx + 4) * E + e];
+      a2 += part[(int64_t)(sidx + 8) * E + e];
+      a3 += part[(int64_t)(sidx + 12) * E + e];
+    }
+    for (; sidx < S; sidx += 4) a0 += part[(int64_t)sidx * E + e];
   }
+  red[wave][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave == 0 && e < E) gw[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // =========================================================================== host dispatch
@@ -360,14 +414,15 @@ static inline int geo_tiles(GeoId g, int B, int H, int W) {
 template <class G, int KS, bool DGRAD>
 int launch_fwd_geo(const float* x, const float* w, const float* bias, float* y, Shape s, hipStream_t st) {
   const int tiles = num_tiles<G>(s.B, s.H, s.W);
+  constexpr bool WK = (G::NPIX == 64);
   // MFMA flavour: 32x32x2 when the output-channel count fills (or nearly fills) 32-row tiles, else 16x16x4
   const bool use32 = (s.Cout % 32 == 0) || s.Cout > 48;
   if (use32) {
-    if (s.Cout > 32) {
+    if (s.Cout > 32 && !WK) {
       dim3 grid(tiles, (s.Cout + 63) / 64);
       conv_fwd_kernel<G, KS, 32, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s);
     } else {
-      dim3 grid(tiles, 1);
+      dim3 grid(tiles, (s.Cout + 31) / 32);
       conv_fwd_kernel<G, KS, 32, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s);
     }
   } else {
@@ -384,10 +439,15 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, float* y, 
 
 template <int KS, bool DGRAD>
 int launch_fwd(const float* x, const float* w, const float* bias, float* y, Shape s, hipStream_t st) {
-  switch (pick_geo(s.H, s.W)) {
-    case GEO_4: return launch_fwd_geo<G4, KS, DGRAD>(x, w, bias, y, s, st);
-    case GEO_8: return launch_fwd_geo<G8, KS, DGRAD>(x, w, bias, y, s, st);
-    case GEO_16: return launch_fwd_geo<G16, KS, DGRAD>(x, w, bias, y, s, st);
+  // small layers: if 256-pixel tiles give fewer than ~2 workgroups per CU, use 64-pixel tiles whose
+  // waves split K (4x the workgroups, each wave 1/4 of the k-groups)
+  const GeoId g = pick_geo(s.H, s.W);
+  const int64_t wgs256 = (int64_t)geo_tiles(g, s.B, s.H, s.W) * ((s.Cout + 63) / 64);
+  const bool ksplit = (g != GEO_X) && wgs256 < 512 && s.Cin >= 16;
+  switch (g) {
+    case GEO_4: return ksplit ? launch_fwd_geo<G4k, KS, DGRAD>(x, w, bias, y, s, st) : launch_fwd_geo<G4, KS, DGRAD>(x, w, bias, y, s, st);
+    case GEO_8: return ksplit ? launch_fwd_geo<G8k, KS, DGRAD>(x, w, bias, y, s, st) : launch_fwd_geo<G8, KS, DGRAD>(x, w, bias, y, s, st);
+    case GEO_16: return ksplit ? launch_fwd_geo<G16k, KS, DGRAD>(x, w, bias, y, s, st) : launch_fwd_geo<G16, KS, DGRAD>(x, w, bias, y, s, st);
     default: return launch_fwd_geo<GX, KS, DGRAD>(x, w, bias, y, s, st);
   }
 }
@@ -403,7 +463,8 @@ static inline WgPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int ks) 
   const int ckw = (ks == 3) ? WgCfg<3>::CKW : WgCfg<1>::CKW;
   p.ci_chunks = (Cin + ckw - 1) / ckw;
   const int groups = p.co_tiles * p.ci_chunks;
-  int S = 1024 / groups;
+  int S = 768 / groups;
+  if (S > 256) S = 256;
   if (S < 1) S = 1;
   if (S > p.tiles) S = p.tiles;
   p.S = S;
@@ -472,7 +533,7 @@ int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* workspace
   const int rc = ks == 3 ? launch_wgrad<3>(x, gy, workspace, s, p, st) : launch_wgrad<1>(x, gy, workspace, s, p, st);
   if (rc != TG_OK) return rc;
   const int64_t E = (int64_t)Cout * Cin * ks * ks;
-  wgrad_reduce_kernel<<<tg_ew_grid(E, 256), 256, 0, st>>>(workspace, gw, E, p.S);
+  wgrad_reduce_kernel<<<(int)((E + 63) / 64), 256, 0, st>>>(workspace, gw, E, p.S);
   return tg_launch_status();
 }
 

@@ -30,6 +30,20 @@ def wrap(name, fn):
         if name in ('bn_train_stats',):       # running stats are in/out; only check mean/invstd
             pre[3] = pre[4] = None
         getattr(E, name)(*pre)
+        if name == 'bn_act_bwd' and args[8] is not None:
+            gz, x, mean, invstd, gamma, beta, slope = pre[:7]
+            B_, C_, HW_ = args[-3:]
+            xv = x.view(B_, C_, HW_)
+            y64 = (xv - mean.view(1, C_, 1)) * invstd.view(1, C_, 1) * gamma.view(1, C_, 1) + beta.view(1, C_, 1)
+            a32 = (gamma.float() * invstd.float()); b32 = beta.float() - mean.float() * a32
+            y32 = torch.addcmul(b32.view(1, C_, 1), xv.float(), a32.view(1, C_, 1))
+            flips = int(((y64 >= 0) != (y32 >= 0)).sum())
+            got = args[8].detach().cpu().double().view(B_, C_, HW_); want = pre[8].view(B_, C_, HW_)
+            d = (got - want).abs()
+            if float(d.max()) > 1e-4 * float(want.abs().max()):
+                idx = torch.nonzero(d > 0.5 * d.max())[:5].tolist()
+                print('BN_BWD', [B_, C_, HW_], 'mask flips', flips, 'n_bad', int((d > 1e-4 * want.abs().max()).sum()), 'worst at', idx,
+                      'per-channel max err (top3):', torch.topk(d.amax((0, 2)), 3), 'y64 near zero count', int((y64.abs() < 1e-5).sum()))
         for i in OUTS[name]:
             if args[i] is None: continue
             want, got = pre[i], args[i].detach().cpu().double()
