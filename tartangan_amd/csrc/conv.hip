@@ -2,18 +2,23 @@
 // gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact fp32,
 // bit-identical to an fmaf chain, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).
 //
-//   forward / dgrad : M = Cout tile, N = 256 output pixels, K = (ci, tap).  The input patch
-//                     (with halo) and the filter slice are staged once per Cin chunk; A/B
-//                     fragments are single ds_read_b32 with compile-time offsets.  dgrad is the
-//                     same kernel reading the filter transposed + spatially flipped.
+//   forward / dgrad : M = Cout tile, N = output pixels, K = (ci, tap).  The input patch (with
+//                     halo) and the filter slice are staged once per Cin chunk; A/B fragments
+//                     are single ds_read_b32 with compile-time offsets.  dgrad is the same
+//                     kernel reading the filter transposed + spatially flipped.
 //   wgrad           : M = Cout tile, N = (ci, tap) columns, K = pixels; each workgroup keeps its
 //                     gw slice in MFMA accumulators while it walks its share of pixel tiles,
 //                     then writes ONE partial; a second kernel sums the partials in a fixed
 //                     order (deterministic, no float atomics).
 //
-// Pixel tiles (256 output pixels per workgroup, 64 per wave):
-//   G4  : 16 whole 4x4 images      G8 : 4 whole 8x8 images     G16 : one 16x16 image
-//   GX  : 8 rows x 32 cols inside one image (any H, W; edges guarded)
+// Staging: 16-byte global loads (whole rows of the NCHW planes are 16-byte aligned when W % 4 == 0)
+// into registers one chunk AHEAD of the MFMA loop, ds_write_b128 into a patch whose interior starts
+// at a 16-byte boundary (halo columns by scalar loads).  Shapes that break the alignment
+// assumptions take a scalar path with identical LDS layout.
+//
+// Pixel tiles:
+//   256 pixels, waves split pixels : G4 (16 4x4 images) G8 (4 8x8) G16 (one 16x16) GX (8 rows x 32)
+//    64 pixels, waves split K       : G4k G8k G16k  -- small-spatial layers still fill the chip
 #include <type_traits>
 
 #include "common.h"
@@ -29,13 +34,12 @@ template <int TH_, int TW_, int NI_>
 struct Geo {
   static constexpr int TH = TH_, TW = TW_, NI = NI_, NPIX = TH_ * TW_ * NI_;
   static_assert(NPIX == 256 || NPIX == 64, "a pixel tile is 256 pixels (waves split pixels) or 64 (waves split K)");
+  static_assert(TW_ % 4 == 0, "rows are staged as float4");
 };
 using G4 = Geo<4, 4, 16>;
 using G8 = Geo<8, 8, 4>;
 using G16 = Geo<16, 16, 1>;
 using GX = Geo<8, 32, 1>;
-// 64-pixel tiles for the small-spatial layers: the 4 waves share the pixels and split the K dimension,
-// so an 8x8 / 16x16 layer still spreads over >= 256 workgroups
 using G4k = Geo<4, 4, 4>;
 using G8k = Geo<8, 8, 1>;
 using G16k = Geo<4, 16, 1>;
@@ -43,12 +47,15 @@ using G16k = Geo<4, 16, 1>;
 template <class G, int KS>
 struct Patch {
   static constexpr int PAD = KS / 2;
-  static constexpr int PH = G::TH + KS - 1, PW = G::TW + KS - 1;
-  static constexpr int PWS = PW;                       // row stride
-  static constexpr int IMG = PH * PWS;                 // one image's patch
+  static constexpr int PH = G::TH + KS - 1;
+  static constexpr int IOFF = (KS == 3) ? 4 : 0;                 // interior column 0 sits at a 16-byte boundary
+  static constexpr int ORG = IOFF - PAD;                         // LDS column of patch column 0 (= image column w0 - PAD)
+  static constexpr int PWS = G::TW + 2 * IOFF;                   // row stride (multiple of 4)
+  static constexpr int IMG = PH * PWS;
   static constexpr int RAW = G::NI * IMG;
-  static constexpr int CIS = ((RAW + 31) / 32) * 32 + 16;   // per-channel stride; %32 == 16 keeps the two
-                                                            // k-halves of a 32-lane LDS group on disjoint banks
+  static constexpr int CIS = ((RAW + 31) / 32) * 32 + 16;        // per-channel stride; %32 == 16 keeps the k-halves of a
+                                                                 // 32-lane LDS group on disjoint banks
+  static constexpr int ROWS_PER_CI = G::NI * PH;
 };
 
 struct Shape {
@@ -77,84 +84,196 @@ static inline int num_tiles(int B, int H, int W) {
   return ((B + G::NI - 1) / G::NI) * ((H + G::TH - 1) / G::TH) * ((W + G::TW - 1) / G::TW);
 }
 
-// offset (inside one channel's patch) of the top-left tap of tile pixel p
+// LDS offset (inside one channel's patch) of the top-left tap of tile pixel p
 template <class G, int KS>
 __device__ __forceinline__ int pix_off(int p) {
   using P = Patch<G, KS>;
   const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
   const int r = rem / G::TW, c = rem % G::TW;
-  return (img * P::PH + r) * P::PWS + c;
+  return (img * P::PH + r) * P::PWS + c + P::ORG;
 }
 
-// stage x[b0.., ci0..ci0+CK, h0-PAD.., w0-PAD..] (zero outside the tensor) into lds[ci][img][r][c]
+// ------------------------------------------------------------------ patch stager
+// x[b0.., c0..c0+CK, h0-PAD.., w0-PAD..] (zero outside the tensor) -> lds[ci][img][r][ORG + c]
 template <class G, int KS, int CK>
-__device__ __forceinline__ void stage_patch(const float* __restrict__ x, float* __restrict__ lds, const Shape& s, int C,
-                                            int ci0, TileCoord tc) {
+struct PatchStager {
   using P = Patch<G, KS>;
-  constexpr int TOTAL = CK * G::NI * P::PH * P::PW;
-  for (int e = threadIdx.x; e < TOTAL; e += CT_THREADS) {
-    const int c = e % P::PW;
-    const int t1 = e / P::PW;
-    const int r = t1 % P::PH;
-    const int t2 = t1 / P::PH;
-    const int img = t2 % G::NI;
-    const int ci = t2 / G::NI;
-    const int b = tc.b0 + img, cc = ci0 + ci, hh = tc.h0 + r - P::PAD, ww = tc.w0 + c - P::PAD;
-    float v = 0.f;
-    if (b < s.B && cc < C && hh >= 0 && hh < s.H && ww >= 0 && ww < s.W)
-      v = x[(((int64_t)b * C + cc) * s.H + hh) * s.W + ww];
-    lds[ci * P::CIS + (img * P::PH + r) * P::PWS + c] = v;
-  }
-}
+  static constexpr int Q = G::TW / 4;
+  static constexpr int ROWS = CK * P::ROWS_PER_CI;
+  static constexpr int NV = (ROWS * Q + CT_THREADS - 1) / CT_THREADS;
+  static constexpr int NHALO = (KS == 3) ? ROWS * 2 : 0;
+  static constexpr int NH = (NHALO + CT_THREADS - 1) / CT_THREADS;
+  float4 v[NV];
+  float hv[NH > 0 ? NH : 1];
 
-// =========================================================================== forward / dgrad
-// CK input channels per chunk; filter slice in LDS as wl[(ci*KK + tap)][co] with row stride CTS.
+  struct RowRef { int ci, lrow; bool ok; int64_t goff; };
+  // row index -> (channel, LDS row, validity, global offset of image column 0 of that row)
+  __device__ __forceinline__ static RowRef row_ref(int row, const Shape& s, int C, int c0, const TileCoord& tc) {
+    const int r = row % P::PH;
+    const int t = row / P::PH;
+    const int img = t % G::NI;
+    const int ci = t / G::NI;
+    const int b = tc.b0 + img, cc = c0 + ci, hh = tc.h0 + r - P::PAD;
+    RowRef o;
+    o.ci = ci;
+    o.lrow = img * P::PH + r;
+    o.ok = (b < s.B) && (cc < C) && (hh >= 0) && (hh < s.H);
+    o.goff = (((int64_t)b * C + cc) * s.H + hh) * s.W;
+    return o;
+  }
+
+  __device__ __forceinline__ void load(const float* __restrict__ x, const Shape& s, int C, int c0, const TileCoord& tc, bool vec) {
+    if (vec) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int e = threadIdx.x + i * CT_THREADS;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < ROWS * Q) {
+          const int q = e % Q;
+          const RowRef rr = row_ref(e / Q, s, C, c0, tc);
+          const int ww = tc.w0 + 4 * q;
+          if (rr.ok && ww < s.W) val = *reinterpret_cast<const float4*>(x + rr.goff + ww);   // W % 4 == 0: all-in or all-out
+        }
+        v[i] = val;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int e = threadIdx.x + i * CT_THREADS;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < ROWS * Q) {
+          const int q = e % Q;
+          const RowRef rr = row_ref(e / Q, s, C, c0, tc);
+          const int ww = tc.w0 + 4 * q;
+          if (rr.ok) {
+            const float* src = x + rr.goff + ww;
+            if (ww < s.W) val.x = src[0];
+            if (ww + 1 < s.W) val.y = src[1];
+            if (ww + 2 < s.W) val.z = src[2];
+            if (ww + 3 < s.W) val.w = src[3];
+          }
+        }
+        v[i] = val;
+      }
+    }
+    if constexpr (KS == 3) {
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        const int e = threadIdx.x + i * CT_THREADS;
+        float val = 0.f;
+        if (e < NHALO) {
+          const RowRef rr = row_ref(e >> 1, s, C, c0, tc);
+          const int ww = (e & 1) ? tc.w0 + G::TW : tc.w0 - 1;
+          if (rr.ok && ww >= 0 && ww < s.W) val = x[rr.goff + ww];
+        }
+        hv[i] = val;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + i * CT_THREADS;
+      if (e < ROWS * Q) {
+        const int q = e % Q, row = e / Q;
+        const int ci = row / P::ROWS_PER_CI, lrow = row % P::ROWS_PER_CI;
+        *reinterpret_cast<float4*>(lds + ci * P::CIS + lrow * P::PWS + P::IOFF + 4 * q) = v[i];
+      }
+    }
+    if constexpr (KS == 3) {
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        const int e = threadIdx.x + i * CT_THREADS;
+        if (e < NHALO) {
+          const int row = e >> 1;
+          const int ci = row / P::ROWS_PER_CI, lrow = row % P::ROWS_PER_CI;
+          lds[ci * P::CIS + lrow * P::PWS + ((e & 1) ? P::IOFF + G::TW : P::IOFF - 1)] = hv[i];
+        }
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------ filter-slice stager
+// LDS: wl[(ci*KK + tap)][co], row stride CTS.  ROWLEN contiguous floats per source row:
+//   forward: row = co,  w[co][ci0..ci0+CK][tap]          (element k = ci*KK + tap)
+//   dgrad  : row = ci,  w[ci][co0..co0+CT][KK-1-tap]     (element k = co*KK + tp), w stored [Cin_eff][Cout_eff][KK]
 template <int KS, bool WK> struct FwdCfg { static constexpr int CK = (KS == 3) ? (WK ? 16 : 8) : 32; };
 
 template <int KS, int CT, bool WK>
 struct WTile {
   static constexpr int KK = KS * KS;
   static constexpr int CK = FwdCfg<KS, WK>::CK;
-  static constexpr int CTS = (CT % 32 == 16) ? CT : CT + 16;   // row stride % 32 == 16: two k-rows of a 32-lane group on disjoint banks
+  static constexpr int CTS = CT + 1;            // odd stride: transposed staging writes and fragment reads both spread over banks
   static constexpr int SIZE = CK * KK * CTS;
 };
 
 template <int KS, int CT, bool DGRAD, bool WK>
-__device__ __forceinline__ void stage_weights(const float* __restrict__ w, float* __restrict__ wl, int Cin, int Cout, int ci0,
-                                              int co0) {
+struct WeightStager {
   using WT = WTile<KS, CT, WK>;
-  constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS;
-  constexpr int TOTAL = CT * CK * KK;
-  for (int e = threadIdx.x; e < TOTAL; e += CT_THREADS) {
-    int co, ci, tap;
-    int64_t src;
-    if (!DGRAD) {
-      // w[co][ci][tap]: for a fixed co the (ci, tap) run is contiguous
-      co = e / (CK * KK);
-      const int r = e - co * (CK * KK);
-      ci = r / KK;
-      tap = r - ci * KK;
-      src = ((int64_t)(co0 + co) * Cin + (ci0 + ci)) * KK + tap;
-    } else {
-      // effective filter weff[co][ci][tap] = w[ci][co][KK-1-tap] with w stored [Cin_eff][Cout_eff][KK]:
-      // for a fixed ci the (co, tap') run is contiguous
-      ci = e / (CT * KK);
-      const int r = e - ci * (CT * KK);
-      co = r / KK;
-      const int tp = r - co * KK;
-      tap = KK - 1 - tp;
-      src = ((int64_t)(ci0 + ci) * Cout + (co0 + co)) * KK + tp;
-    }
-    float v = 0.f;
-    if (co0 + co < Cout && ci0 + ci < Cin) v = w[src];
-    wl[(ci * KK + tap) * CTS + co] = v;
-  }
-}
+  static constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS;
+  static constexpr int NROWS = DGRAD ? CK : CT;
+  static constexpr int ROWLEN = DGRAD ? CT * KK : CK * KK;
+  static_assert(ROWLEN % 4 == 0, "filter rows are staged as float4");
+  static constexpr int Q = ROWLEN / 4;
+  static constexpr int NV = (NROWS * Q + CT_THREADS - 1) / CT_THREADS;
+  float4 v[NV];
 
+  __device__ __forceinline__ void load(const float* __restrict__ w, int Cin, int Cout, int ci0, int co0, bool vec) {
+    // valid elements per row (ragged last chunk / last channel tile)
+    const int nvalid = (DGRAD ? min(CT, Cout - co0) : min(CK, Cin - ci0)) * KK;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + i * CT_THREADS;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < NROWS * Q) {
+        const int q = e % Q, row = e / Q;
+        const bool row_ok = DGRAD ? (ci0 + row < Cin) : (co0 + row < Cout);
+        if (row_ok) {
+          const int64_t base = DGRAD ? ((int64_t)(ci0 + row) * Cout + co0) * KK : ((int64_t)(co0 + row) * Cin + ci0) * KK;
+          const float* src = w + base + 4 * q;
+          if (vec && 4 * q + 3 < nvalid) {
+            val = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (4 * q < nvalid) val.x = src[0];
+            if (4 * q + 1 < nvalid) val.y = src[1];
+            if (4 * q + 2 < nvalid) val.z = src[2];
+            if (4 * q + 3 < nvalid) val.w = src[3];
+          }
+        }
+      }
+      v[i] = val;
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ wl) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + i * CT_THREADS;
+      if (e < NROWS * Q) {
+        const int q = e % Q, row = e / Q;
+        const float vals[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = 4 * q + u;
+          if (!DGRAD) {
+            wl[k * CTS + row] = vals[u];                                   // k = ci*KK + tap, row = co
+          } else {
+            const int co = k / KK, tp = k % KK;
+            wl[(row * KK + (KK - 1 - tp)) * CTS + co] = vals[u];           // row = ci
+          }
+        }
+      }
+    }
+  }
+};
+
+// =========================================================================== forward / dgrad
 template <class G, int KS, int MF, int MT, bool DGRAD>
 __global__ void __launch_bounds__(CT_THREADS)
 conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-                Shape s) {
+                Shape s, int vec_x, int vec_w) {
   using P = Patch<G, KS>;
   constexpr bool WK = (G::NPIX == 64);        // waves split K (same pixels) instead of pixels
   constexpr int CT = MF * MT;
@@ -168,7 +287,7 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
   static_assert(!WK || NG % 4 == 0, "K-split needs a multiple of 4 k-groups per chunk");
   constexpr int STAGE = CK * P::CIS + WT::SIZE;
   constexpr int REDF = WK ? 4 * MT * NT * NREG * 64 : 0;
-  __shared__ float lds[STAGE > REDF ? STAGE : REDF];
+  __shared__ __attribute__((aligned(16))) float lds[STAGE > REDF ? STAGE : REDF];
   float* pl = lds;
   float* wl = lds + CK * P::CIS;
 
@@ -193,11 +312,20 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
 #pragma unroll
       for (int r = 0; r < NREG; ++r) acc[m][n][r] = 0.f;
 
+  PatchStager<G, KS, CK> ps;
+  WeightStager<KS, CT, DGRAD, WK> ws;
+  ps.load(x, s, s.Cin, 0, tc, vec_x);
+  ws.load(w, s.Cin, s.Cout, 0, co0, vec_w);
+
   for (int ci0 = 0; ci0 < s.Cin; ci0 += CK) {
+    __syncthreads();                          // every wave is done reading the previous chunk
+    ps.store(pl);
+    ws.store(wl);
     __syncthreads();
-    stage_patch<G, KS, CK>(x, pl, s, s.Cin, ci0, tc);
-    stage_weights<KS, CT, DGRAD, WK>(w, wl, s.Cin, s.Cout, ci0, co0);
-    __syncthreads();
+    if (ci0 + CK < s.Cin) {                   // next chunk's global loads fly under this chunk's MFMAs
+      ps.load(x, s, s.Cin, ci0 + CK, tc, vec_x);
+      ws.load(w, s.Cin, s.Cout, ci0 + CK, co0, vec_w);
+    }
     // skip all-zero k-groups of a ragged last chunk (wave-uniform)
     const int kgroups = (min(CK, s.Cin - ci0) + KG - 1) / KG;
 #pragma unroll
@@ -227,8 +355,7 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
   }
 
   if constexpr (WK) {
-    // sum the four waves' partial accumulators through LDS (fixed order); wave w keeps registers
-    // [w*NREG/4, (w+1)*NREG/4) of every (m, n) tile for the store below
+    // sum the four waves' partial accumulators through LDS (fixed order)
     __syncthreads();
     float* red = lds;
 #pragma unroll
@@ -279,18 +406,68 @@ template <int KS> struct WgCfg {
   static constexpr int NCOL = CKW * KK;                // (ci, tap) columns
   static constexpr int NT = (NCOL + 15) / 16;
 };
-constexpr int WG_GYS = 256 + 2;    // gy tile row stride: 16 co x 2 pixels of a 32-lane group hit 32 distinct banks
+constexpr int WG_GYS = 256 + 4;    // gy tile row stride (multiple of 4 for ds_write_b128; %32 == 4: 2-way at worst on A reads)
+
+// gy tile stager: gy[b0.., co0..co0+CT, h0.., w0..] -> gl[co][p], p = (img*TH + r)*TW + c
+template <class G, int CT>
+struct GyStager {
+  static constexpr int Q = G::TW / 4;
+  static constexpr int ROWS_PER_CO = G::NI * G::TH;
+  static constexpr int ROWS = CT * ROWS_PER_CO;
+  static constexpr int NV = (ROWS * Q + CT_THREADS - 1) / CT_THREADS;
+  float4 v[NV];
+
+  __device__ __forceinline__ void load(const float* __restrict__ gy, const Shape& s, int co0, const TileCoord& tc, bool vec) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + i * CT_THREADS;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < ROWS * Q) {
+        const int q = e % Q, row = e / Q;
+        const int r = row % G::TH;
+        const int t = row / G::TH;
+        const int img = t % G::NI, co = t / G::NI;
+        const int b = tc.b0 + img, hh = tc.h0 + r, ww = tc.w0 + 4 * q;
+        if (b < s.B && co0 + co < s.Cout && hh < s.H && ww < s.W) {
+          const float* src = gy + (((int64_t)b * s.Cout + co0 + co) * s.H + hh) * s.W + ww;
+          if (vec) {
+            val = *reinterpret_cast<const float4*>(src);
+          } else {
+            val.x = src[0];
+            if (ww + 1 < s.W) val.y = src[1];
+            if (ww + 2 < s.W) val.z = src[2];
+            if (ww + 3 < s.W) val.w = src[3];
+          }
+        }
+      }
+      v[i] = val;
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ gl) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + i * CT_THREADS;
+      if (e < ROWS * Q) {
+        const int q = e % Q, row = e / Q;
+        const int co = row / ROWS_PER_CO, prow = row % ROWS_PER_CO;
+        *reinterpret_cast<float4*>(gl + co * WG_GYS + prow * G::TW + 4 * q) = v[i];
+      }
+    }
+  }
+};
 
 template <class G, int KS, int MTW>
 __global__ void __launch_bounds__(CT_THREADS)
-conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, Shape s, int ntiles, int S) {
+conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, Shape s, int ntiles, int S,
+                  int vec_x, int vec_gy) {
   using P = Patch<G, KS>;
   using C = WgCfg<KS>;
   constexpr int CKW = C::CKW, KK = C::KK, NT = C::NT, CT = 16 * MTW;
   constexpr int PATCH = CKW * P::CIS, GYT = CT * WG_GYS;
   constexpr int RED = 4 * MTW * NT * 4 * 64;           // cross-wave reduction: 4 waves x (MTW*NT*4 regs) x 64 lanes
   constexpr int LDS_FLOATS = (PATCH + GYT) > RED ? (PATCH + GYT) : RED;
-  __shared__ float lds[LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* pl = lds;
   float* gl = lds + PATCH;
 
@@ -316,21 +493,23 @@ conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, flo
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  PatchStager<G, KS, CKW> ps;
+  GyStager<G, CT> gs;
+  if (split < ntiles) {
+    const TileCoord tc = decode_tile<G>(split, s.H, s.W);
+    ps.load(x, s, s.Cin, ci0, tc, vec_x);
+    gs.load(gy, s, co0, tc, vec_gy);
+  }
   for (int t = split; t < ntiles; t += S) {
-    const TileCoord tc = decode_tile<G>(t, s.H, s.W);
     __syncthreads();
-    stage_patch<G, KS, CKW>(x, pl, s, s.Cin, ci0, tc);
-    // gy tile: gl[co][p]
-    for (int e = threadIdx.x; e < CT * 256; e += CT_THREADS) {
-      const int p = e & 255, co = e >> 8;
-      const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
-      const int b = tc.b0 + img, hh = tc.h0 + rem / G::TW, ww = tc.w0 + rem % G::TW;
-      float v = 0.f;
-      if (b < s.B && hh < s.H && ww < s.W && co0 + co < s.Cout)
-        v = gy[(((int64_t)b * s.Cout + co0 + co) * s.H + hh) * s.W + ww];
-      gl[co * WG_GYS + p] = v;
+    ps.store(pl);
+    gs.store(gl);
+    __syncthreads();
+    if (t + S < ntiles) {
+      const TileCoord tn = decode_tile<G>(t + S, s.H, s.W);
+      ps.load(x, s, s.Cin, ci0, tn, vec_x);
+      gs.load(gy, s, co0, tn, vec_gy);
     }
-    __syncthreads();
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       // pixel group 64*wave + 4g .. +3: same row (TW % 4 == 0); offset relative to the wave's first pixel
@@ -411,27 +590,38 @@ static inline int geo_tiles(GeoId g, int B, int H, int W) {
   }
 }
 
+// 16-byte row loads need W % 4 == 0 and a 16-byte aligned base
+static inline int plane_vec_ok(const void* p, int W) { return (W % 4 == 0) && tg_aligned16(p); }
+
 template <class G, int KS, bool DGRAD>
 int launch_fwd_geo(const float* x, const float* w, const float* bias, float* y, Shape s, hipStream_t st) {
   const int tiles = num_tiles<G>(s.B, s.H, s.W);
   constexpr bool WK = (G::NPIX == 64);
+  const int vx = plane_vec_ok(x, s.W);
+  // filter rows start at multiples of (channels * KK) floats: 16-byte aligned iff that channel count is a multiple of 4
+  const int vw = tg_aligned16(w) && ((DGRAD ? s.Cout : s.Cin) % 4 == 0);
   // MFMA flavour: 32x32x2 when the output-channel count fills (or nearly fills) 32-row tiles, else 16x16x4
   const bool use32 = (s.Cout % 32 == 0) || s.Cout > 48;
   if (use32) {
-    if (s.Cout > 32 && !WK) {
-      dim3 grid(tiles, (s.Cout + 63) / 64);
-      conv_fwd_kernel<G, KS, 32, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s);
-    } else {
+    bool done = false;
+    if constexpr (!WK) {
+      if (s.Cout > 32) {
+        dim3 grid(tiles, (s.Cout + 63) / 64);
+        conv_fwd_kernel<G, KS, 32, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s, vx, vw);
+        done = true;
+      }
+    }
+    if (!done) {
       dim3 grid(tiles, (s.Cout + 31) / 32);
-      conv_fwd_kernel<G, KS, 32, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s);
+      conv_fwd_kernel<G, KS, 32, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s, vx, vw);
     }
   } else {
     if (s.Cout > 16) {
       dim3 grid(tiles, (s.Cout + 31) / 32);
-      conv_fwd_kernel<G, KS, 16, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s);
+      conv_fwd_kernel<G, KS, 16, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s, vx, vw);
     } else {
       dim3 grid(tiles, 1);
-      conv_fwd_kernel<G, KS, 16, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s);
+      conv_fwd_kernel<G, KS, 16, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s, vx, vw);
     }
   }
   return tg_launch_status();
@@ -474,8 +664,9 @@ static inline WgPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int ks) 
 template <class G, int KS>
 int launch_wgrad_geo(const float* x, const float* gy, float* part, Shape s, const WgPlan& p, hipStream_t st) {
   dim3 grid(p.S, p.co_tiles, p.ci_chunks);
-  if (p.mtw == 2) conv_wgrad_kernel<G, KS, 2><<<grid, CT_THREADS, 0, st>>>(x, gy, part, s, p.tiles, p.S);
-  else conv_wgrad_kernel<G, KS, 1><<<grid, CT_THREADS, 0, st>>>(x, gy, part, s, p.tiles, p.S);
+  const int vx = plane_vec_ok(x, s.W), vg = plane_vec_ok(gy, s.W);
+  if (p.mtw == 2) conv_wgrad_kernel<G, KS, 2><<<grid, CT_THREADS, 0, st>>>(x, gy, part, s, p.tiles, p.S, vx, vg);
+  else conv_wgrad_kernel<G, KS, 1><<<grid, CT_THREADS, 0, st>>>(x, gy, part, s, p.tiles, p.S, vx, vg);
   return tg_launch_status();
 }
 
