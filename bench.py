@@ -74,7 +74,9 @@ class KernelTimer:
     def __enter__(self):
         for name in ('conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad', 'bn_train_stats', 'bn_act_fwd', 'bn_act_bwd',
                      'bn_act_dbwd', 'gemm', 'softmax_fwd', 'softmax_bwd', 'softmax_dbwd', 'up2x', 'pool2',
-                     'bilinear_half_fwd', 'bilinear_half_bwd', 'add', 'channel_sum', 'adam_step', 'ema'):
+                     'bilinear_half_fwd', 'bilinear_half_bwd', 'add', 'channel_sum', 'adam_step', 'ema', 'attn_fwd', 'attn_bwd',
+                     'maxpool2_fwd', 'maxpool2_bwd', 'scale_add_dev', 'dot', 'scale_dev', 'mul', 'lrelu_bwd', 'tanh_fwd', 'tanh_bwd',
+                     'row_sum', 'row_bcast', 'bce_logits', 'sumsq', 'fill', 'scale', 'channel_bcast'):
             fn = getattr(self.K, name)
             self._saved[name] = fn
             setattr(self.K, name, self._wrap(name, fn))

@@ -152,6 +152,19 @@ int tg_softmax_bwd(const float* gy, const float* y, float* gs, int rows, int col
  * out = v*gy - v*sum(gy*y) - gy*sum(v*y)                                        */
 int tg_softmax_dbwd(const float* v, const float* gy, const float* y, float* out, int rows, int cols, void* stream);
 
+/* ---------------------------------------------------------------- fused attention core (attention.py:27-34)
+ * o = g softmax_m(theta^T phi)^T without materialising the (N x M) map.
+ * theta (B,D,N), phi (B,D,M), g (B,DV,M), o (B,DV,N), lse (B,N) = log sum_m exp(score).
+ * Compiled for (D,DV) in {(1,4),(2,8),(4,16),(8,32),(16,64)} (C = 8..128); others: TG_EUNSUPPORTED
+ * (the host then composes tg_gemm / tg_softmax_*).  _bwd is the first-order backward;
+ * workspace: B*N floats.  The second-order path recomputes through the composed primitives. */
+int tg_attn_supported(int D, int DV);
+int tg_attn_fwd(const float* theta, const float* phi, const float* g, float* o, float* lse,
+                int B, int D, int DV, int N, int M, void* stream);
+int tg_attn_bwd(const float* go, const float* theta, const float* phi, const float* g, const float* o,
+                const float* lse, float* dtheta, float* dphi, float* dg, float* workspace,
+                int B, int D, int DV, int N, int M, void* stream);
+
 /* ---------------------------------------------------------------- IQN head (models/iqn.py)
  * out[i][j] = cos((taus[i] * pi) * range[j])   iqn.py:41-45 (fp32, this evaluation order) */
 int tg_iqn_cos_embed(const float* taus, const float* range, float* out, int n, int dims, void* stream);

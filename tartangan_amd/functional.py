@@ -738,6 +738,51 @@ def softmax_lastdim(s):
     return _Softmax.apply(s)
 
 
+# =========================================================================== fused attention core
+def attention_composed(theta, phi, g):
+    """g softmax(theta^T phi)^T from differentiable-twice primitives; materialises the (N x M) map."""
+    beta = softmax_lastdim(matmul(theta, phi, transA=True))          # (B, N, M)
+    return matmul(g, beta, transB=True)                               # (B, DV, N)
+
+
+class _AttnCore(Function):
+    @staticmethod
+    def forward(ctx, theta, phi, g):
+        theta, phi, g = theta.contiguous(), phi.contiguous(), g.contiguous()
+        B, D, N = theta.shape
+        DV, M = g.shape[1], g.shape[2]
+        o = theta.new_empty(B, DV, N)
+        lse = theta.new_empty(B, N)
+        K().attn_fwd(theta, phi, g, o, lse, B, D, DV, N, M)
+        ctx.save_for_backward(theta, phi, g, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        theta, phi, g, o, lse = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            # create_graph=True (R1 penalty on the real branch): the backward itself must be differentiable,
+            # so recompute through the composed primitives, which carry second-order kernels
+            inputs = [t for t, need in zip((theta, phi, g), ctx.needs_input_grad) if need]
+            with torch.enable_grad():
+                grads = torch.autograd.grad(attention_composed(theta, phi, g), inputs, go, create_graph=True)
+            it = iter(grads)
+            return tuple(next(it) if need else None for need in ctx.needs_input_grad)
+        go = go.contiguous()
+        B, D, N = theta.shape
+        DV, M = g.shape[1], g.shape[2]
+        dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
+        K().attn_bwd(go, theta, phi, g, o, lse, dtheta, dphi, dg, _ws(go, B * N * 4), B, D, DV, N, M)
+        return dtheta, dphi, dg
+
+
+def attention_core(theta, phi, g):
+    """theta (B,D,N), phi (B,D,M), g (B,DV,M) -> (B,DV,N).  Fused kernel when the head dims are compiled in."""
+    if K().attn_supported(theta.shape[1], g.shape[1]):
+        return _AttnCore.apply(theta, phi, g)
+    return attention_composed(theta, phi, g)
+
+
 # =========================================================================== IQN / losses
 def iqn_cos_embed(taus, embedding_range):
     """cos((tau*pi)*range) -- no gradient (taus are sampled, range is a buffer)."""

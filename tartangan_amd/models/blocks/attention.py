@@ -4,8 +4,9 @@ theta/phi/g/o are bias-free 1x1 convolutions, phi and g are 2x2 max-pooled, the
 (N x N/4) attention map is a row softmax of theta^T phi and the block returns
 gamma * o(g beta^T) + x with a learnable scalar gamma initialised to 0.
 
-This composition is differentiable twice (every primitive is a transpose pair or
-has an explicit second-order kernel), which the discriminator's R1 penalty needs.
+The attention core runs in one fused kernel that never materialises the (N x N/4) map
+(forward and first-order backward).  Under the discriminator's R1 penalty the backward has to
+be differentiable itself; there it is recomputed from primitives that carry second-order kernels.
 """
 import torch
 from torch import nn
@@ -31,6 +32,5 @@ class SelfAttention2d(nn.Module):
         theta = self.theta(x).view(b, c // 8, n)
         phi = TF.max_pool2(self.phi(x)).view(b, c // 8, n // 4)
         g = TF.max_pool2(self.g(x)).view(b, c // 2, n // 4)
-        beta = TF.softmax_lastdim(TF.matmul(theta, phi, transA=True))       # (b, n, n/4)
-        o = TF.matmul(g, beta, transB=True).view(b, c // 2, h, w)           # g beta^T
+        o = TF.attention_core(theta, phi, g).view(b, c // 2, h, w)          # g softmax(theta^T phi)^T
         return TF.scale_add(self.gamma, self.o(o), x)

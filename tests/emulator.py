@@ -259,6 +259,24 @@ class Emulator:
         _v(out, rows, cols).copy_(vv * g - vv * d - g * e)
         return 0
 
+    # ---------------------------------------------------------------- fused attention core
+    def attn_supported(self, D, DV):
+        return int((D, DV) in ((1, 4), (2, 8), (4, 16), (8, 32), (16, 64)))
+
+    def attn_fwd(self, theta, phi, g, o, lse, B, D, DV, N, M):
+        s = torch.bmm(theta.view(B, D, N).transpose(1, 2), phi.view(B, D, M))
+        lse.view(B, N).copy_(torch.logsumexp(s, -1))
+        o.view(B, DV, N).copy_(torch.bmm(g.view(B, DV, M), F.softmax(s, -1).transpose(1, 2)))
+        return 0
+
+    def attn_bwd(self, go, theta, phi, g, o, lse, dtheta, dphi, dg, ws, B, D, DV, N, M):
+        with torch.enable_grad():
+            t, p, gg = (a.detach().clone().requires_grad_() for a in (theta.view(B, D, N), phi.view(B, D, M), g.view(B, DV, M)))
+            out = torch.bmm(gg, F.softmax(torch.bmm(t.transpose(1, 2), p), -1).transpose(1, 2))
+            a, b, c = torch.autograd.grad(out, (t, p, gg), go.view(B, DV, N).detach())
+        dtheta.view(B, D, N).copy_(a); dphi.view(B, D, M).copy_(b); dg.view(B, DV, M).copy_(c)
+        return 0
+
     # ---------------------------------------------------------------- iqn / losses
     def iqn_cos_embed(self, taus, rng, out, n, dims):
         out.copy_(torch.cos(taus.view(n, 1).repeat(1, dims) * math.pi * rng))

@@ -235,6 +235,28 @@ def test_softmax(K, shape):
     run_both(K, 'softmax_dbwd', [v, gy, y, torch.zeros(rows, cols), rows, cols], [3], tol=1e-5)
 
 
+@pytest.mark.parametrize('dims', [(3, 4, 16, 1024, 256), (2, 16, 64, 256, 64), (2, 16, 64, 64, 16), (2, 1, 4, 1024, 256),
+                                  (1, 4, 16, 4096, 1024), (2, 8, 32, 300, 75), (1, 2, 8, 64, 16)])
+def test_fused_attention(K, dims):
+    B, D, DV, N, M = dims
+    assert K.attn_supported(D, DV)
+    theta, phi, g = rnd(B, D, N), rnd(B, D, M, seed=1), rnd(B, DV, M, seed=2)
+    o, lse = torch.zeros(B, DV, N), torch.zeros(B, N)
+    run_both(K, 'attn_fwd', [theta, phi, g, o, lse, B, D, DV, N, M], [3, 4], tol=6e-6)   # online softmax + v_exp_f32
+    E.attn_fwd(theta, phi, g, o, lse, B, D, DV, N, M)
+    go = rnd(B, DV, N, seed=3)
+    ws = workspace(B * N * 4)
+    run_both(K, 'attn_bwd', [go, theta, phi, g, o, lse, torch.zeros(B, D, N), torch.zeros(B, D, M), torch.zeros(B, DV, M),
+                             ws, B, D, DV, N, M], [6, 7, 8], tol=2e-5)
+
+
+def test_fused_attention_unsupported_dims(K):
+    assert not K.attn_supported(3, 12)
+    with pytest.raises(RuntimeError):
+        K.attn_fwd(rnd(1, 3, 16).cuda(), rnd(1, 3, 4).cuda(), rnd(1, 12, 4).cuda(), torch.zeros(1, 12, 16).cuda(),
+                   torch.zeros(1, 16).cuda(), 1, 3, 12, 16, 4)
+
+
 def test_iqn_and_losses(K):
     Q, B = 8, 24
     taus = torch.rand(Q * B, 1)
