@@ -46,22 +46,26 @@ int tg_conv2d_fwd(const float* x, const float* w, const float* bias /*nullable*/
 int tg_conv2d_dgrad(const float* gy, const float* w, float* gx,
                     int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 /* gw[co][ci][kh][kw] = sum_{b,h,w} gy[b,co,h,w] * x[b,ci,h+kh-p,w+kw-p]
- * (convolution_backward grad_weight); deterministic two-stage reduction.      */
+ * (convolution_backward grad_weight) and, when gbias != NULL, gbias[co] = sum_{b,h,w} gy (grad_bias) from
+ * the same pass; deterministic two-stage reduction.  accumulate != 0: add into gw / gbias instead of
+ * overwriting (gradient accumulation straight into the flat .grad bucket).                              */
 size_t tg_conv2d_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ks);
-int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* workspace, size_t workspace_bytes,
-                    int B, int Cin, int Cout, int H, int W, int ks, void* stream);
-/* out[c] = sum_{b,p} x[b][c][p]   (conv / linear bias grad); workspace: tg_bn_workspace(B,C,HW) bytes */
-int tg_channel_sum(const float* x, float* out, float* workspace, int B, int C, int HW, void* stream);
+int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* gbias /*nullable*/,
+                    float* workspace, size_t workspace_bytes,
+                    int B, int Cin, int Cout, int H, int W, int ks, int accumulate, void* stream);
+/* out[c] (+)= sum_{b,p} x[b][c][p]   (linear bias grad); workspace: tg_bn_workspace(B,C,HW) bytes */
+int tg_channel_sum(const float* x, float* out, float* workspace, int B, int C, int HW, int accumulate,
+                   void* stream);
 /* out[b][c][p] = v[c] (transpose of tg_channel_sum) */
 int tg_channel_bcast(const float* v, float* out, int B, int C, int HW, void* stream);
 
 /* ---------------------------------------------------------------- GEMM
  * nn.Linear (generator.py:70-72, discriminator.py:137-139,158-160, iqn.py:33-35)
- * and torch.bmm (attention.py:32,34).  Row-major; C[b] = op(A[b]) op(B[b]) (+ bias[n]).
+ * and torch.bmm (attention.py:32,34).  Row-major; C[b] = op(A[b]) op(B[b]) (+ bias[n]) + beta*C[b].
  * op(A) is MxK, op(B) is KxN; lda/ldb/ldc are row strides of the stored arrays. */
 int tg_gemm(const float* A, const float* Bm, float* C, const float* bias_n /*nullable*/,
             int M, int N, int K, int lda, int ldb, int ldc, int transA, int transB,
-            int batch, int64_t strideA, int64_t strideB, int64_t strideC, void* stream);
+            int batch, int64_t strideA, int64_t strideB, int64_t strideC, float beta, void* stream);
 
 /* ---------------------------------------------------------------- BatchNorm2d (+LeakyReLU)
  * nn.BatchNorm2d train mode followed by nn.LeakyReLU(0.2): generator.py:38-44,
@@ -69,9 +73,10 @@ int tg_gemm(const float* A, const float* Bm, float* C, const float* bias_n /*nul
  * Workspace: tg_bn_workspace(B,C,HW) bytes.                                       */
 size_t tg_bn_workspace(int B, int C, int HW);
 /* batch mean / 1/sqrt(biased var + eps); optional running-stat update
- * (running_var uses the unbiased variance, momentum as nn.BatchNorm2d)         */
+ * (running_var uses the unbiased variance, momentum as nn.BatchNorm2d); *num_batches_tracked += 1 */
 int tg_bn_train_stats(const float* x, float* mean, float* invstd,
                       float* running_mean /*nullable*/, float* running_var /*nullable*/,
+                      int64_t* num_batches_tracked /*nullable*/,
                       float momentum, float eps, float* workspace, int B, int C, int HW, void* stream);
 /* eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps) */
 int tg_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd,
@@ -85,7 +90,7 @@ int tg_bn_act_fwd(const float* x, const float* mean, const float* invstd, const 
 int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const float* invstd,
                   const float* gamma, const float* beta, float slope, int training,
                   float* gx /*nullable*/, float* ggamma, float* gbeta, float* workspace,
-                  int B, int C, int HW, void* stream);
+                  int B, int C, int HW, int accumulate /* ggamma, gbeta += */, void* stream);
 /* second backward of the training-mode map (gz, x, gamma) -> (gx, ggamma, gbeta)
  * (NativeBatchNormBackwardBackward0; R1 penalty path, models/losses.py:23-26).
  * v = adjoint of gx, vgamma/vbeta = adjoints of ggamma/gbeta (nullable = 0).   */
@@ -136,7 +141,8 @@ int tg_scale_dev(const float* s, float alpha, const float* x, float* out, int64_
 int tg_scale_add_dev(const float* s, const float* a, const float* b, float* out, int64_t n, void* stream);
 /* *out = alpha * sum_i a[i]*b[i]  (deterministic two-stage; workspace tg_reduce_workspace(n)) */
 size_t tg_reduce_workspace(int64_t n);
-int tg_dot(const float* a, const float* b, float alpha, float* out, float* workspace, int64_t n, void* stream);
+int tg_dot(const float* a, const float* b, float alpha, float* out, float* workspace, int64_t n,
+           int accumulate, void* stream);
 /* out = g * (x >= 0 ? 1 : slope)  (LeakyReLU fwd when g == x; leaky_relu_backward otherwise) */
 int tg_lrelu_bwd(const float* g, const float* x, float slope, float* out, int64_t n, void* stream);
 int tg_tanh_fwd(const float* x, float* y, int64_t n, void* stream);

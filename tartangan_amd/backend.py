@@ -21,7 +21,7 @@ LIBRARY = os.path.join(_HERE, 'csrc', 'libtartangan_amd.so')
 
 _CTYPES = {
     'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p,
-    'const uint8_t*': ctypes.c_void_p, 'uint8_t*': ctypes.c_void_p,
+    'const uint8_t*': ctypes.c_void_p, 'uint8_t*': ctypes.c_void_p, 'int64_t*': ctypes.c_void_p,
     'void*': ctypes.c_void_p, 'int': ctypes.c_int, 'int64_t': ctypes.c_int64,
     'size_t': ctypes.c_size_t, 'float': ctypes.c_float, 'const char*': ctypes.c_char_p,
 }

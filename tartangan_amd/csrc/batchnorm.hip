@@ -52,9 +52,10 @@ struct RedStats {
 };
 
 __global__ void stats_stage2(const double* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
-                             float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv, float momentum,
-                             float eps, int B, int C, int HW, int S) {
+                             float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv,
+                             int64_t* __restrict__ nbt, float momentum, float eps, int B, int C, int HW, int S) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt != nullptr) *nbt += 1;
   if (c >= C) return;
   const double n = (double)B * HW;
   const double pivot = (double)x[(int64_t)c * HW];
@@ -133,14 +134,14 @@ struct RedBwd {
 };
 
 __global__ void bwd_stage2(const double* __restrict__ partial, float* __restrict__ ggamma, float* __restrict__ gbeta,
-                           float* __restrict__ coef, int B, int C, int HW, int S) {
+                           float* __restrict__ coef, int B, int C, int HW, int S, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double n = (double)B * HW;
   const double sb = planes::gather(partial, c, S, 2, 0);
   const double sg = planes::gather(partial, c, S, 2, 1);
-  gbeta[c] = (float)sb;
-  ggamma[c] = (float)sg;
+  gbeta[c] = (float)sb + (accumulate ? gbeta[c] : 0.f);
+  ggamma[c] = (float)sg + (accumulate ? ggamma[c] : 0.f);
   coef[c * COEF + 0] = (float)(sb / n);
   coef[c * COEF + 1] = (float)(sg / n);
 }
@@ -270,8 +271,9 @@ size_t tg_bn_workspace(int B, int C, int HW) {
   return (size_t)C * S * MAXK * sizeof(double) + (size_t)C * COEF * sizeof(float);
 }
 
-int tg_bn_train_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var, float momentum,
-                      float eps, float* workspace, int B, int C, int HW, void* stream) {
+int tg_bn_train_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float momentum, float eps, float* workspace, int B, int C, int HW,
+                      void* stream) {
   TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(workspace);
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   if ((running_mean == nullptr) != (running_var == nullptr)) return TG_EINVAL;
@@ -279,7 +281,7 @@ int tg_bn_train_stats(const float* x, float* mean, float* invstd, float* running
   Parts p = split_ws(workspace, B, C, HW);
   RedStats red{x, C, HW, 0.f};
   planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x));
-  stats_stage2<<<chan_grid(C), 64, 0, st>>>(p.partial, x, mean, invstd, running_mean, running_var, momentum, eps, B, C, HW,
+  stats_stage2<<<chan_grid(C), 64, 0, st>>>(p.partial, x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, B, C, HW,
                                             planes::splits(B, C, HW));
   return tg_launch_status();
 }
@@ -303,7 +305,7 @@ int tg_bn_act_fwd(const float* x, const float* mean, const float* invstd, const 
 
 int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, float slope, int training, float* gx, float* ggamma, float* gbeta, float* workspace,
-                  int B, int C, int HW, void* stream) {
+                  int B, int C, int HW, int accumulate, void* stream) {
   TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta);
   TG_CHECK_PTR(ggamma); TG_CHECK_PTR(gbeta); TG_CHECK_PTR(workspace);
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
@@ -311,7 +313,7 @@ int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const floa
   Parts p = split_ws(workspace, B, C, HW);
   RedBwd red{gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
   planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz));
-  bwd_stage2<<<chan_grid(C), 64, 0, st>>>(p.partial, ggamma, gbeta, p.coef, B, C, HW, planes::splits(B, C, HW));
+  bwd_stage2<<<chan_grid(C), 64, 0, st>>>(p.partial, ggamma, gbeta, p.coef, B, C, HW, planes::splits(B, C, HW), accumulate);
   if (gx != nullptr) {
     BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, training};
     planes::launch_map(body, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx));

@@ -455,12 +455,20 @@ struct GyStager {
       }
     }
   }
+
+  // bias gradient for free: a 256-pixel tile is 64 float4 per channel, so register i of wave w holds
+  // nothing but channel 4*i + w -- one wavefront reduction per register adds the tile's sum_p gy[co][p].
+  static_assert(ROWS_PER_CO * Q == 64, "one channel of a gy tile = one wave's worth of float4");
+  __device__ __forceinline__ void add_channel_sums(float* acc /*[NV]*/) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] += wave_sum((v[i].x + v[i].y) + (v[i].z + v[i].w));
+  }
 };
 
 template <class G, int KS, int MTW>
 __global__ void __launch_bounds__(CT_THREADS)
-conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, Shape s, int ntiles, int S,
-                  int vec_x, int vec_gy) {
+conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part,
+                  float* __restrict__ bias_part /*nullable: [S][Cout]*/, Shape s, int ntiles, int S, int vec_x, int vec_gy) {
   using P = Patch<G, KS>;
   using C = WgCfg<KS>;
   constexpr int CKW = C::CKW, KK = C::KK, NT = C::NT, CT = 16 * MTW;
@@ -495,6 +503,10 @@ conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, flo
 
   PatchStager<G, KS, CKW> ps;
   GyStager<G, CT> gs;
+  const bool do_bias = (bias_part != nullptr) && (blockIdx.z == 0);
+  float bsum[GyStager<G, CT>::NV];
+#pragma unroll
+  for (int i = 0; i < GyStager<G, CT>::NV; ++i) bsum[i] = 0.f;
   if (split < ntiles) {
     const TileCoord tc = decode_tile<G>(split, s.H, s.W);
     ps.load(x, s, s.Cin, ci0, tc, vec_x);
@@ -504,6 +516,7 @@ conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, flo
     __syncthreads();
     ps.store(pl);
     gs.store(gl);
+    if (do_bias) gs.add_channel_sums(bsum);
     __syncthreads();
     if (t + S < ntiles) {
       const TileCoord tn = decode_tile<G>(t + S, s.H, s.W);
@@ -528,6 +541,13 @@ conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, flo
     }
   }
 
+  if (do_bias && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < GyStager<G, CT>::NV; ++i) {
+      const int co = co0 + 4 * i + wave;
+      if (4 * i + wave < CT && co < s.Cout) bias_part[(int64_t)split * s.Cout + co] = bsum[i];
+    }
+  }
   // cross-wave reduction through LDS (fixed order), then one partial write per workgroup
   __syncthreads();
   float* red = lds;                                            // [wave][m][n][r][lane]
@@ -551,26 +571,39 @@ conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, flo
   }
 }
 
-// gw[e] = sum_s part[s][e], fixed order.  64 consecutive e per workgroup (coalesced), the S partials
+// gw[e] (+)= sum_s part[s][e], fixed order.  64 consecutive e per workgroup (coalesced), the S partials
 // are split over the 4 waves and combined through LDS: no serial chain of S dependent loads.
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int64_t E, int S) {
+// Workgroups past ceil(E/64) reduce the bias partials the same way.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int64_t E, int S,
+                                                           const float* __restrict__ bias_part, float* __restrict__ gbias, int Cout,
+                                                           int accumulate) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t e = blockIdx.x * 64ll + lane;
+  const int eblocks = (int)((E + 63) / 64);
+  const float* src = part;
+  float* dst = gw;
+  int64_t n = E, e = blockIdx.x * 64ll + lane;
+  if ((int)blockIdx.x >= eblocks) {
+    src = bias_part; dst = gbias; n = Cout;
+    e = (blockIdx.x - eblocks) * 64ll + lane;
+  }
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (e < E) {
+  if (e < n) {
     int sidx = wave;
     for (; sidx + 12 < S; sidx += 16) {
-      a0 += part[(int64_t)sidx * E + e];
-      a1 += part[(int64_t)(sidx + 4) * E + e];
-      a2 += part[(int64_t)(sidx + 8) * E + e];
-      a3 += part[(int64_t)(sidx + 12) * E + e];
+      a0 += src[(int64_t)sidx * n + e];
+      a1 += src[(int64_t)(sidx + 4) * n + e];
+      a2 += src[(int64_t)(sidx + 8) * n + e];
+      a3 += src[(int64_t)(sidx + 12) * n + e];
     }
-    for (; sidx < S; sidx += 4) a0 += part[(int64_t)sidx * E + e];
+    for (; sidx < S; sidx += 4) a0 += src[(int64_t)sidx * n + e];
   }
   red[wave][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (wave == 0 && e < E) gw[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0 && e < n) {
+    const float r = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    dst[e] = accumulate ? dst[e] + r : r;
+  }
 }
 
 // =========================================================================== host dispatch
@@ -662,21 +695,21 @@ static inline WgPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int ks) 
 }
 
 template <class G, int KS>
-int launch_wgrad_geo(const float* x, const float* gy, float* part, Shape s, const WgPlan& p, hipStream_t st) {
+int launch_wgrad_geo(const float* x, const float* gy, float* part, float* bias_part, Shape s, const WgPlan& p, hipStream_t st) {
   dim3 grid(p.S, p.co_tiles, p.ci_chunks);
   const int vx = plane_vec_ok(x, s.W), vg = plane_vec_ok(gy, s.W);
-  if (p.mtw == 2) conv_wgrad_kernel<G, KS, 2><<<grid, CT_THREADS, 0, st>>>(x, gy, part, s, p.tiles, p.S, vx, vg);
-  else conv_wgrad_kernel<G, KS, 1><<<grid, CT_THREADS, 0, st>>>(x, gy, part, s, p.tiles, p.S, vx, vg);
+  if (p.mtw == 2) conv_wgrad_kernel<G, KS, 2><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S, vx, vg);
+  else conv_wgrad_kernel<G, KS, 1><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S, vx, vg);
   return tg_launch_status();
 }
 
 template <int KS>
-int launch_wgrad(const float* x, const float* gy, float* part, Shape s, const WgPlan& p, hipStream_t st) {
+int launch_wgrad(const float* x, const float* gy, float* part, float* bias_part, Shape s, const WgPlan& p, hipStream_t st) {
   switch (pick_geo(s.H, s.W)) {
-    case GEO_4: return launch_wgrad_geo<G4, KS>(x, gy, part, s, p, st);
-    case GEO_8: return launch_wgrad_geo<G8, KS>(x, gy, part, s, p, st);
-    case GEO_16: return launch_wgrad_geo<G16, KS>(x, gy, part, s, p, st);
-    default: return launch_wgrad_geo<GX, KS>(x, gy, part, s, p, st);
+    case GEO_4: return launch_wgrad_geo<G4, KS>(x, gy, part, bias_part, s, p, st);
+    case GEO_8: return launch_wgrad_geo<G8, KS>(x, gy, part, bias_part, s, p, st);
+    case GEO_16: return launch_wgrad_geo<G16, KS>(x, gy, part, bias_part, s, p, st);
+    default: return launch_wgrad_geo<GX, KS>(x, gy, part, bias_part, s, p, st);
   }
 }
 
@@ -710,21 +743,23 @@ int tg_conv2d_dgrad(const float* gy, const float* w, float* gx, int B, int Cin, 
 size_t tg_conv2d_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ks) {
   if (check_shape(B, Cin, Cout, H, W, ks) != TG_OK) return 0;
   const WgPlan p = wgrad_plan(B, Cin, Cout, H, W, ks);
-  return (size_t)p.S * Cout * Cin * ks * ks * sizeof(float);
+  return ((size_t)p.S * Cout * Cin * ks * ks + (size_t)p.S * Cout) * sizeof(float);
 }
 
-int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* workspace, size_t workspace_bytes, int B, int Cin,
-                    int Cout, int H, int W, int ks, void* stream) {
+int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* gbias, float* workspace, size_t workspace_bytes, int B,
+                    int Cin, int Cout, int H, int W, int ks, int accumulate, void* stream) {
   TG_CHECK_PTR(x); TG_CHECK_PTR(gy); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
   if (int rc = check_shape(B, Cin, Cout, H, W, ks)) return rc;
   if (workspace_bytes < tg_conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks)) return TG_EWORKSPACE;
   const WgPlan p = wgrad_plan(B, Cin, Cout, H, W, ks);
   Shape s{B, Cin, Cout, H, W};
   hipStream_t st = tg_stream(stream);
-  const int rc = ks == 3 ? launch_wgrad<3>(x, gy, workspace, s, p, st) : launch_wgrad<1>(x, gy, workspace, s, p, st);
-  if (rc != TG_OK) return rc;
   const int64_t E = (int64_t)Cout * Cin * ks * ks;
-  wgrad_reduce_kernel<<<(int)((E + 63) / 64), 256, 0, st>>>(workspace, gw, E, p.S);
+  float* bias_part = gbias ? workspace + (size_t)p.S * E : nullptr;
+  const int rc = ks == 3 ? launch_wgrad<3>(x, gy, workspace, bias_part, s, p, st) : launch_wgrad<1>(x, gy, workspace, bias_part, s, p, st);
+  if (rc != TG_OK) return rc;
+  const int blocks = (int)((E + 63) / 64) + (gbias ? (Cout + 63) / 64 : 0);
+  wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(workspace, gw, E, p.S, bias_part, gbias, Cout, accumulate);
   return tg_launch_status();
 }
 

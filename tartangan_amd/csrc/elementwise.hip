@@ -109,12 +109,12 @@ __global__ void __launch_bounds__(RED_BLOCK) reduce_stage1(const float* __restri
 }
 
 __global__ void __launch_bounds__(RED_BLOCK) reduce_stage2(const double* __restrict__ partial, int nparts, double alpha,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, int accumulate = 0) {
   __shared__ double scratch[32];
   double acc = 0.0;
   for (int i = threadIdx.x; i < nparts; i += RED_BLOCK) acc += partial[i];
   acc = block_sum_d(acc, scratch);
-  if (threadIdx.x == 0) *out = (float)(alpha * acc);
+  if (threadIdx.x == 0) *out = (float)(alpha * acc) + (accumulate ? *out : 0.f);
 }
 
 static inline int red_grid(int64_t n) {
@@ -125,13 +125,13 @@ static inline int red_grid(int64_t n) {
 }
 
 template <class R>
-int launch_reduce(const float* a, const float* b, double alpha, float* out, float* ws, int64_t n, void* stream, R r) {
+int launch_reduce(const float* a, const float* b, double alpha, float* out, float* ws, int64_t n, void* stream, R r, int accumulate = 0) {
   TG_CHECK_PTR(a); TG_CHECK_PTR(out); TG_CHECK_PTR(ws);
   if (n <= 0) return TG_EINVAL;
   double* partial = reinterpret_cast<double*>(ws);
   const int g = red_grid(n);
   reduce_stage1<R><<<g, RED_BLOCK, 0, tg_stream(stream)>>>(a, b, partial, n, r);
-  reduce_stage2<<<1, RED_BLOCK, 0, tg_stream(stream)>>>(partial, g, alpha, out);
+  reduce_stage2<<<1, RED_BLOCK, 0, tg_stream(stream)>>>(partial, g, alpha, out, accumulate);
   return tg_launch_status();
 }
 
@@ -239,9 +239,9 @@ int tg_fill(float* x, float value, int64_t n, void* stream) { return launch_unar
 
 size_t tg_reduce_workspace(int64_t n) { (void)n; return (size_t)RED_MAX_BLOCKS * sizeof(double); }
 
-int tg_dot(const float* a, const float* b, float alpha, float* out, float* workspace, int64_t n, void* stream) {
+int tg_dot(const float* a, const float* b, float alpha, float* out, float* workspace, int64_t n, int accumulate, void* stream) {
   TG_CHECK_PTR(b);
-  return launch_reduce(a, b, (double)alpha, out, workspace, n, stream, RedDot{});
+  return launch_reduce(a, b, (double)alpha, out, workspace, n, stream, RedDot{}, accumulate);
 }
 int tg_sumsq(const float* x, float alpha, float* out, float* workspace, int64_t n, void* stream) {
   return launch_reduce(x, nullptr, (double)alpha, out, workspace, n, stream, RedSumSq{});

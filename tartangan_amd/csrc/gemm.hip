@@ -12,7 +12,7 @@ constexpr int BM = 64, BN = 64, BK = 16, GT = 256;
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(GT) gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
                                                   const float* __restrict__ bias, int M, int N, int K, int lda, int ldb, int ldc,
-                                                  int64_t sA, int64_t sB, int64_t sC) {
+                                                  int64_t sA, int64_t sB, int64_t sC, float beta) {
   __shared__ float As[BK][BM + 4];
   __shared__ float Bs[BK][BN + 4];
   const int batch = blockIdx.z;
@@ -67,7 +67,11 @@ __global__ void __launch_bounds__(GT) gemm_kernel(const float* __restrict__ A, c
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int gn = n0 + tx * 4 + j;
-      if (gn < N) C[(int64_t)gm * ldc + gn] = acc[i][j] + (bias ? bias[gn] : 0.f);
+      if (gn < N) {
+        float r = acc[i][j] + (bias ? bias[gn] : 0.f);
+        if (beta != 0.f) r += beta * C[(int64_t)gm * ldc + gn];
+        C[(int64_t)gm * ldc + gn] = r;
+      }
     }
   }
 }
@@ -76,16 +80,16 @@ __global__ void __launch_bounds__(GT) gemm_kernel(const float* __restrict__ A, c
 
 extern "C" int tg_gemm(const float* A, const float* Bm, float* C, const float* bias_n, int M, int N, int K, int lda, int ldb,
                        int ldc, int transA, int transB, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
-                       void* stream) {
+                       float beta, void* stream) {
   TG_CHECK_PTR(A); TG_CHECK_PTR(Bm); TG_CHECK_PTR(C);
   TG_CHECK_POS(M); TG_CHECK_POS(N); TG_CHECK_POS(K); TG_CHECK_POS(batch);
   if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return TG_EINVAL;
   if (batch > 65535) return TG_EUNSUPPORTED;
   dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
   hipStream_t st = tg_stream(stream);
-  if (transA && transB) gemm_kernel<true, true><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC);
-  else if (transA) gemm_kernel<true, false><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC);
-  else if (transB) gemm_kernel<false, true><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC);
-  else gemm_kernel<false, false><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC);
+  if (transA && transB) gemm_kernel<true, true><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
+  else if (transA) gemm_kernel<true, false><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
+  else if (transB) gemm_kernel<false, true><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
+  else gemm_kernel<false, false><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
   return tg_launch_status();
 }

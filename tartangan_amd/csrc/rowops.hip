@@ -26,9 +26,9 @@ struct RedChan {
   __device__ void acc1(int64_t off, float* a) { a[0] += x[off]; }
 };
 
-__global__ void chan_stage2(const double* __restrict__ partial, float* __restrict__ out, int C, int S) {
+__global__ void chan_stage2(const double* __restrict__ partial, float* __restrict__ out, int C, int S, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) out[c] = (float)planes::gather(partial, c, S, 1, 0);
+  if (c < C) out[c] = (float)planes::gather(partial, c, S, 1, 0) + (accumulate ? out[c] : 0.f);
 }
 
 struct BcastBody {
@@ -130,13 +130,13 @@ __global__ void __launch_bounds__(RB) softmax_dbwd_kernel(const float* __restric
 
 extern "C" {
 
-int tg_channel_sum(const float* x, float* out, float* workspace, int B, int C, int HW, void* stream) {
+int tg_channel_sum(const float* x, float* out, float* workspace, int B, int C, int HW, int accumulate, void* stream) {
   TG_CHECK_PTR(x); TG_CHECK_PTR(out); TG_CHECK_PTR(workspace);
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   hipStream_t st = tg_stream(stream);
   double* partial = reinterpret_cast<double*>(workspace);
   planes::launch_reduce(RedChan{x}, partial, B, C, HW, st, tg_aligned16(x));
-  chan_stage2<<<(C + 63) / 64, 64, 0, st>>>(partial, out, C, planes::splits(B, C, HW));
+  chan_stage2<<<(C + 63) / 64, 64, 0, st>>>(partial, out, C, planes::splits(B, C, HW), accumulate);
   return tg_launch_status();
 }
 

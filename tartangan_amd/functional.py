@@ -28,6 +28,23 @@ def _ws(like, nbytes):
     return torch.empty(max(1, (int(nbytes) + 3) // 4), dtype=torch.float32, device=like.device)
 
 
+def _grad_sink(p):
+    """Where a parameter gradient can be accumulated in place, or None.
+
+    In a plain ``.backward()`` (no create_graph) the gradient of a leaf parameter that already owns
+    a ``.grad`` buffer (tartangan_amd.optim keeps them as views of one flat bucket per network) is
+    written by the producing kernel straight into that buffer with accumulate semantics, and the
+    Function returns ``None`` for it.  That is exactly what autograd's AccumulateGrad would do with a
+    returned tensor, minus one temporary and one elementwise-add launch per parameter.
+    """
+    if p is None or torch.is_grad_enabled() or not (p.is_leaf and p.requires_grad):
+        return None
+    g = p.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+        return None
+    return g
+
+
 # =========================================================================== conv
 class _ConvFwd(Function):
     @staticmethod
@@ -37,21 +54,26 @@ class _ConvFwd(Function):
         Cout, ks = w.shape[0], w.shape[2]
         y = x.new_empty(B, Cout, H, W)
         K().conv2d_fwd(x, w, bias, y, B, Cin, Cout, H, W, ks)
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, bias)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, bias = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gw = gb = None
+        need_w = ctx.needs_input_grad[1]
+        need_b = bias is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[0]:
             gx = _ConvDgrad.apply(gy, w)
-        if ctx.needs_input_grad[1]:
-            gw = _ConvWgrad.apply(x, gy, w.shape[2])
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = _ChannelSum.apply(gy)
+        sink_w, sink_b = _grad_sink(w), _grad_sink(bias)
+        if need_w and sink_w is not None and (not need_b or sink_b is not None):
+            _conv_wgrad_into(x, gy, sink_w, sink_b if need_b else None, w.shape[2], accumulate=1)
+        else:
+            if need_w:
+                gw = _ConvWgrad.apply(x, gy, w.shape[2])
+            if need_b:
+                gb = _ChannelSum.apply(gy)
         return gx, gw, gb
 
 
@@ -78,16 +100,19 @@ class _ConvDgrad(Function):
         return a_gy, a_w
 
 
+def _conv_wgrad_into(x, gy, gw, gbias, ks, accumulate):
+    B, Cin, H, W = x.shape
+    Cout = gy.shape[1]
+    ws = _ws(x, K().conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks))
+    K().conv2d_wgrad(x, gy, gw, gbias, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks, accumulate)
+
+
 class _ConvWgrad(Function):
     @staticmethod
     def forward(ctx, x, gy, ks):
         x, gy = x.contiguous(), gy.contiguous()
-        B, Cin, H, W = x.shape
-        Cout = gy.shape[1]
-        gw = x.new_empty(Cout, Cin, ks, ks)
-        nbytes = K().conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks)
-        ws = _ws(x, nbytes)
-        K().conv2d_wgrad(x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks)
+        gw = x.new_empty(gy.shape[1], x.shape[1], ks, ks)
+        _conv_wgrad_into(x, gy, gw, None, ks, accumulate=0)
         ctx.save_for_backward(x, gy)
         return gw
 
@@ -110,7 +135,7 @@ class _ChannelSum(Function):
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         out = x.new_empty(C)
-        K().channel_sum(x, out, _ws(x, K().bn_workspace(B, C, hw)), B, C, hw)
+        K().channel_sum(x, out, _ws(x, K().bn_workspace(B, C, hw)), B, C, hw, 0)
         ctx.shape = x.shape
         return out
 
@@ -156,7 +181,7 @@ class _Gemm(Function):
         shape = (batch, M, N) if A.dim() == 3 else (M, N)
         C = A.new_empty(shape)
         K().gemm(A, Bm, C, None, M, N, Kd, ac, bc, N, int(ta), int(tb), batch,
-                 ar * ac, br * bc, M * N)
+                 ar * ac, br * bc, M * N, 0.0)
         ctx.save_for_backward(A, Bm)
         ctx.ta, ctx.tb = ta, tb
         return C
@@ -184,21 +209,32 @@ class _Linear(Function):
         M, Kd = x.shape
         N = w.shape[0]
         y = x.new_empty(M, N)
-        K().gemm(x, w, y, bias, M, N, Kd, Kd, Kd, N, 0, 1, 1, 0, 0, 0)
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
+        K().gemm(x, w, y, bias, M, N, Kd, Kd, Kd, N, 0, 1, 1, 0, 0, 0, 0.0)
+        ctx.save_for_backward(x, w, bias)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, bias = ctx.saved_tensors
+        gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = _Gemm.apply(gy, w, False, False)
         if ctx.needs_input_grad[1]:
-            gw = _Gemm.apply(gy, x, True, False)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = _ChannelSum.apply(gy)
+            sink = _grad_sink(w)
+            if sink is not None:          # gw += gy^T x straight into the flat bucket
+                M, N = gy.shape
+                Kd = x.shape[1]
+                K().gemm(gy, x, sink, None, N, Kd, M, N, Kd, Kd, 1, 0, 1, 0, 0, 0, 1.0)
+            else:
+                gw = _Gemm.apply(gy, x, True, False)
+        if bias is not None and ctx.needs_input_grad[2]:
+            sink = _grad_sink(bias)
+            if sink is not None:
+                M, N = gy.shape
+                K().channel_sum(gy, sink, _ws(gy, K().bn_workspace(M, N, 1)), M, N, 1, 1)
+            else:
+                gb = _ChannelSum.apply(gy)
         return gx, gw, gb
 
 
@@ -209,15 +245,15 @@ def linear(x, weight, bias=None):
 # =========================================================================== BatchNorm (+LeakyReLU)
 class _BNAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, num_batches_tracked=None):
         x = x.contiguous()
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         mean, invstd = x.new_empty(C), x.new_empty(C)
         if training:
             ws = _ws(x, K().bn_workspace(B, C, hw))
-            K().bn_train_stats(x, mean, invstd, running_mean, running_var, float(momentum), float(eps),
-                               ws, B, C, hw)
+            K().bn_train_stats(x, mean, invstd, running_mean, running_var, num_batches_tracked,
+                               float(momentum), float(eps), ws, B, C, hw)
         else:
             K().bn_eval_stats(running_mean, running_var, mean, invstd, float(eps), C)
         z = torch.empty_like(x)
@@ -229,9 +265,20 @@ class _BNAct(Function):
     @staticmethod
     def backward(ctx, gz):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
+        sink_g, sink_b = _grad_sink(gamma), _grad_sink(beta)
+        if sink_g is not None and sink_b is not None:
+            # plain backward: ggamma / gbeta accumulate straight into the flat bucket
+            gz = gz.contiguous()
+            B, C = x.shape[0], x.shape[1]
+            hw = x[0, 0].numel()
+            gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            ws = _ws(x, K().bn_workspace(B, C, hw))
+            K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, ctx.slope, int(ctx.training), gx, sink_g, sink_b, ws,
+                           B, C, hw, 1)
+            return gx, None, None, None, None, None, None, None, None, None
         gx, gg, gb = _BNActBwd.apply(gz, x, gamma, beta, mean, invstd, ctx.slope, ctx.training,
                                      ctx.needs_input_grad[0])
-        return gx, gg, gb, None, None, None, None, None, None
+        return gx, gg, gb, None, None, None, None, None, None, None
 
 
 class _BNActBwd(Function):
@@ -243,7 +290,7 @@ class _BNActBwd(Function):
         gx = torch.empty_like(x) if need_gx else None
         gg, gb = x.new_empty(C), x.new_empty(C)
         ws = _ws(x, K().bn_workspace(B, C, hw))
-        K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, slope, int(training), gx, gg, gb, ws, B, C, hw)
+        K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, slope, int(training), gx, gg, gb, ws, B, C, hw, 0)
         ctx.save_for_backward(gz, x, gamma, beta, mean, invstd)
         ctx.slope, ctx.training = slope, training
         return gx, gg, gb
@@ -264,9 +311,12 @@ class _BNActBwd(Function):
         return a_gz, a_x, a_gamma, None, None, None, None, None, None
 
 
-def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, slope=1.0):
-    """BatchNorm2d followed by LeakyReLU(slope) in one pass (slope=1: plain BN)."""
-    return _BNAct.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, slope)
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, slope=1.0,
+                   num_batches_tracked=None):
+    """BatchNorm2d followed by LeakyReLU(slope) in one pass (slope=1: plain BN).  In training mode the
+    stats kernel also bumps ``num_batches_tracked`` (int64 device scalar) when given."""
+    return _BNAct.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, slope,
+                        num_batches_tracked)
 
 
 # =========================================================================== resampling
@@ -569,7 +619,7 @@ class _Dot(Function):
         a, b = a.contiguous(), b.contiguous()
         out = a.new_empty(())
         ws = _ws(a, K().reduce_workspace(a.numel()))
-        K().dot(a, b, alpha, out, ws, a.numel())
+        K().dot(a, b, alpha, out, ws, a.numel(), 0)
         ctx.save_for_backward(a, b)
         ctx.alpha = alpha
         return out
@@ -597,7 +647,14 @@ class _ScaleAddDev(Function):
     @staticmethod
     def backward(ctx, g):
         s, a = ctx.saved_tensors
-        gs = _Dot.apply(g, a, 1.0).reshape(s.shape) if ctx.needs_input_grad[0] else None
+        gs = None
+        if ctx.needs_input_grad[0]:
+            sink = _grad_sink(s)
+            if sink is not None:
+                gc = g.contiguous()
+                K().dot(gc, a, 1.0, sink, _ws(a, K().reduce_workspace(a.numel())), a.numel(), 1)
+            else:
+                gs = _Dot.apply(g, a, 1.0).reshape(s.shape)
         ga = _ScaleDev.apply(s, g, 1.0) if ctx.needs_input_grad[1] else None
         return gs, ga, g
 

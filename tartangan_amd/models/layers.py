@@ -64,11 +64,9 @@ class BatchNorm2d(nn.BatchNorm2d):
     def _run(self, x, slope):
         if self.momentum is None or not self.affine or not self.track_running_stats:
             raise NotImplementedError('tartangan_amd.BatchNorm2d: default nn.BatchNorm2d options only')
-        training = self.training
-        if training:
-            self.num_batches_tracked.add_(1)
         return TF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                 training, self.momentum, self.eps, slope)
+                                 self.training, self.momentum, self.eps, slope,
+                                 self.num_batches_tracked if self.training else None)
 
     def forward(self, x):
         return self._run(x, 1.0)

@@ -34,13 +34,17 @@ class Emulator:
     def conv2d_wgrad_workspace(self, B, Cin, Cout, H, W, ks):
         return 16
 
-    def conv2d_wgrad(self, x, gy, gw, ws, ws_bytes, B, Cin, Cout, H, W, ks):
-        gw.copy_(torch.nn.grad.conv2d_weight(_v(x, B, Cin, H, W), (Cout, Cin, ks, ks),
-                                             _v(gy, B, Cout, H, W), padding=ks // 2))
+    def conv2d_wgrad(self, x, gy, gw, gbias, ws, ws_bytes, B, Cin, Cout, H, W, ks, accumulate):
+        r = torch.nn.grad.conv2d_weight(_v(x, B, Cin, H, W), (Cout, Cin, ks, ks), _v(gy, B, Cout, H, W), padding=ks // 2)
+        gw.copy_(gw + r if accumulate else r)
+        if gbias is not None:
+            rb = _v(gy, B, Cout, H * W).sum((0, 2))
+            gbias.copy_(gbias + rb if accumulate else rb)
         return 0
 
-    def channel_sum(self, x, out, ws, B, C, HW):
-        out.copy_(_v(x, B, C, HW).sum((0, 2)))
+    def channel_sum(self, x, out, ws, B, C, HW, accumulate):
+        r = _v(x, B, C, HW).sum((0, 2))
+        out.copy_(out + r if accumulate else r)
         return 0
 
     def channel_bcast(self, v, out, B, C, HW):
@@ -48,7 +52,7 @@ class Emulator:
         return 0
 
     # ---------------------------------------------------------------- gemm
-    def gemm(self, A, Bm, C, bias, M, N, K, lda, ldb, ldc, ta, tb, batch, sA, sB, sC):
+    def gemm(self, A, Bm, C, bias, M, N, K, lda, ldb, ldc, ta, tb, batch, sA, sB, sC, beta):
         a = A.reshape(batch, -1, lda)
         b = Bm.reshape(batch, -1, ldb)
         a = a.transpose(1, 2) if ta else a
@@ -56,6 +60,8 @@ class Emulator:
         r = torch.bmm(a, b)
         if bias is not None:
             r = r + bias.view(1, 1, N)
+        if beta != 0:
+            r = r + beta * C.view(batch, M, N)
         C.view(batch, M, N).copy_(r)
         return 0
 
@@ -63,7 +69,9 @@ class Emulator:
     def bn_workspace(self, B, C, HW):
         return 16
 
-    def bn_train_stats(self, x, mean, invstd, rm, rv, momentum, eps, ws, B, C, HW):
+    def bn_train_stats(self, x, mean, invstd, rm, rv, nbt, momentum, eps, ws, B, C, HW):
+        if nbt is not None:
+            nbt.add_(1)
         xv = _v(x, B, C, HW)
         n = B * HW
         m = xv.mean((0, 2))
@@ -93,14 +101,14 @@ class Emulator:
         _v(z, B, C, HW).copy_(y * s)
         return 0
 
-    def bn_act_bwd(self, gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, ws, B, C, HW):
+    def bn_act_bwd(self, gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, ws, B, C, HW, accumulate):
         xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
         gyh = _v(gz, B, C, HW) * s
         n = B * HW
         sb = gyh.sum((0, 2))
         sg = (gyh * xhat).sum((0, 2))
-        gg.copy_(sg)
-        gb.copy_(sb)
+        gg.copy_(gg + sg if accumulate else sg)
+        gb.copy_(gb + sb if accumulate else sb)
         if gx is not None:
             k = (gamma * invstd).view(1, C, 1)
             if training:
@@ -222,8 +230,9 @@ class Emulator:
     def reduce_workspace(self, n):
         return 16
 
-    def dot(self, a, b, alpha, out, ws, n):
-        out.copy_(alpha * (a.double() * b.double()).sum().float())
+    def dot(self, a, b, alpha, out, ws, n, accumulate):
+        r = alpha * (a.double() * b.double()).sum().to(a.dtype)
+        out.copy_(out + r if accumulate else r)
         return 0
 
     def lrelu_bwd(self, g, x, slope, out, n):

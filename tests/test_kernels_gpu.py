@@ -90,8 +90,13 @@ def test_conv_wgrad(K, shape):
     nbytes = K.conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks)
     assert nbytes > 0
     ws = torch.zeros(nbytes // 4 + 4)
-    run_both(K, 'conv2d_wgrad', [x, gy, torch.zeros(Cout, Cin, ks, ks), ws, ws.numel() * 4, B, Cin, Cout, H, W, ks],
-             [2], tol=5e-5, scratch=[3])
+    run_both(K, 'conv2d_wgrad', [x, gy, torch.zeros(Cout, Cin, ks, ks), None, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks, 0],
+             [2], tol=5e-5, scratch=[4])
+    # fused bias gradient + accumulate-into-existing (the flat .grad bucket path)
+    run_both(K, 'conv2d_wgrad', [x, gy, rnd(Cout, Cin, ks, ks, seed=9), rnd(Cout, seed=10), ws, ws.numel() * 4,
+                                 B, Cin, Cout, H, W, ks, 1], [2, 3], tol=5e-5, scratch=[4])
+    run_both(K, 'conv2d_wgrad', [x, gy, rnd(Cout, Cin, ks, ks, seed=9), rnd(Cout, seed=10), ws, ws.numel() * 4,
+                                 B, Cin, Cout, H, W, ks, 0], [2, 3], tol=5e-5, scratch=[4])
 
 
 def test_conv_wgrad_is_deterministic(K):
@@ -101,7 +106,7 @@ def test_conv_wgrad_is_deterministic(K):
     outs = []
     for _ in range(3):
         gw = torch.zeros(Cout, Cin, ks, ks).cuda()
-        K.conv2d_wgrad(x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks)
+        K.conv2d_wgrad(x, gy, gw, None, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks, 0)
         outs.append(gw.cpu())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
@@ -123,17 +128,18 @@ def test_batchnorm_all_passes(K, shape):
     rm, rv = 0.05 * rnd(C, seed=2), 1 + 0.1 * torch.rand(C)
     ws = workspace(K.bn_workspace(B, C, HW))
     mean, invstd = torch.zeros(C), torch.zeros(C)
-    run_both(K, 'bn_train_stats', [x, mean, invstd, rm, rv, 0.1, 1e-5, ws, B, C, HW], [1, 2, 3, 4], tol=1e-5)
-    E.bn_train_stats(x, mean, invstd, None, None, 0.1, 1e-5, None, B, C, HW)
+    nbt = torch.tensor(41, dtype=torch.int64)
+    run_both(K, 'bn_train_stats', [x, mean, invstd, rm, rv, nbt, 0.1, 1e-5, ws, B, C, HW], [1, 2, 3, 4, 5], tol=1e-5)
+    E.bn_train_stats(x, mean, invstd, None, None, None, 0.1, 1e-5, None, B, C, HW)
     run_both(K, 'bn_eval_stats', [rm, rv, torch.zeros(C), torch.zeros(C), 1e-5, C], [2, 3], tol=1e-6)
     for slope in (0.2, 1.0):
         run_both(K, 'bn_act_fwd', [x, mean, invstd, gamma, beta, slope, torch.zeros(B, C, HW), B, C, HW], [6], tol=1e-5)
         gz = rnd(B, C, HW, seed=5)
         for training in (1, 0):
             run_both(K, 'bn_act_bwd', [gz, x, mean, invstd, gamma, beta, slope, training, torch.zeros(B, C, HW),
-                                       torch.zeros(C), torch.zeros(C), ws, B, C, HW], [8, 9, 10], tol=3e-5)
-        run_both(K, 'bn_act_bwd', [gz, x, mean, invstd, gamma, beta, slope, 1, None, torch.zeros(C), torch.zeros(C),
-                                   ws, B, C, HW], [9, 10], tol=3e-5)
+                                       torch.zeros(C), torch.zeros(C), ws, B, C, HW, 0], [8, 9, 10], tol=3e-5)
+        run_both(K, 'bn_act_bwd', [gz, x, mean, invstd, gamma, beta, slope, 1, None, rnd(C, seed=11), rnd(C, seed=12),
+                                   ws, B, C, HW, 1], [9, 10], tol=3e-5)
         v = rnd(B, C, HW, seed=6)
         for vg, vb in ((rnd(C, seed=7), rnd(C, seed=8)), (None, None)):
             run_both(K, 'bn_act_dbwd', [v, vg, vb, gz, x, mean, invstd, gamma, beta, slope, torch.zeros(B, C, HW),
@@ -177,17 +183,20 @@ def test_gemm(K, case):
     lda, ldb = A.shape[-1], Bm.shape[-1]
     for bias in (None, rnd(N, seed=2)):
         run_both(K, 'gemm', [A, Bm, torch.zeros(batch, M, N), bias, M, N, Kd, lda, ldb, N, ta, tb, batch,
-                             A[0].numel(), Bm[0].numel(), M * N], [2], tol=2e-5)
+                             A[0].numel(), Bm[0].numel(), M * N, 0.0], [2], tol=2e-5)
+    run_both(K, 'gemm', [A, Bm, rnd(batch, M, N, seed=5), None, M, N, Kd, lda, ldb, N, ta, tb, batch,
+                         A[0].numel(), Bm[0].numel(), M * N, 1.0], [2], tol=2e-5)
 
 
 def test_row_and_channel_ops(K):
     B, C, HW = 5, 12, 48
     x = rnd(B, C, HW)
     ws = workspace(K.bn_workspace(B, C, HW))
-    run_both(K, 'channel_sum', [x, torch.zeros(C), ws, B, C, HW], [1], tol=1e-5)
+    run_both(K, 'channel_sum', [x, torch.zeros(C), ws, B, C, HW, 0], [1], tol=1e-5)
+    run_both(K, 'channel_sum', [x, rnd(C, seed=4), ws, B, C, HW, 1], [1], tol=1e-5)
     xb = rnd(3, 16, 64 * 64)
     wsb = workspace(K.bn_workspace(3, 16, 64 * 64))
-    run_both(K, 'channel_sum', [xb, torch.zeros(16), wsb, 3, 16, 64 * 64], [1], tol=1e-5)
+    run_both(K, 'channel_sum', [xb, torch.zeros(16), wsb, 3, 16, 64 * 64, 0], [1], tol=1e-5)
     run_both(K, 'channel_bcast', [rnd(C), torch.zeros(B, C, HW), B, C, HW], [1], atol=0.0)
     run_both(K, 'channel_bcast', [rnd(16), torch.zeros(3, 16, 64 * 64), 3, 16, 64 * 64], [1], atol=0.0)
     run_both(K, 'row_sum', [x, torch.zeros(B * C), 1.0, B * C, HW], [1], tol=1e-5)
@@ -207,7 +216,8 @@ def test_elementwise(K):
         run_both(K, 'scale_dev', [s, 0.5, a, torch.zeros(n), n], [3], tol=1e-6)
         run_both(K, 'scale_add_dev', [s, a, b, torch.zeros(n), n], [3], tol=1e-6)
         ws = workspace(K.reduce_workspace(n))
-        run_both(K, 'dot', [a, b, 0.5, torch.zeros(()), ws, n], [3], tol=1e-5, atol=1e-5 * n ** 0.5)
+        run_both(K, 'dot', [a, b, 0.5, torch.zeros(()), ws, n, 0], [3], tol=1e-5, atol=1e-5 * n ** 0.5)
+        run_both(K, 'dot', [a, b, 0.5, torch.tensor(3.0), ws, n, 1], [3], tol=1e-5, atol=1e-5 * n ** 0.5)
         run_both(K, 'sumsq', [a, 0.25, torch.zeros(()), ws, n], [2], tol=1e-5)
         run_both(K, 'lrelu_bwd', [a, b, 0.2, torch.zeros(n), n], [3], atol=0.0)
         y = torch.tanh(a)
