@@ -163,8 +163,10 @@ int tg_softmax_dbwd(const float* v, const float* gy, const float* y, float* out,
  * theta (B,D,N), phi (B,D,M), g (B,DV,M), o (B,DV,N), lse (B,N) = log sum_m exp(score).
  * Compiled for (D,DV) in {(1,4),(2,8),(4,16),(8,32),(16,64)} (C = 8..128); others: TG_EUNSUPPORTED
  * (the host then composes tg_gemm / tg_softmax_*).  _bwd is the first-order backward;
- * workspace: B*N floats.  The second-order path recomputes through the composed primitives. */
+ * workspace: tg_attn_bwd_workspace() bytes.  The second-order path recomputes through the composed
+ * primitives.                                                                                          */
 int tg_attn_supported(int D, int DV);
+size_t tg_attn_bwd_workspace(int B, int D, int DV, int N, int M);
 int tg_attn_fwd(const float* theta, const float* phi, const float* g, float* o, float* lse,
                 int B, int D, int DV, int N, int M, void* stream);
 int tg_attn_bwd(const float* go, const float* theta, const float* phi, const float* g, const float* o,

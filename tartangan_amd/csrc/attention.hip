@@ -156,7 +156,10 @@ template <int D, int DV>
 __global__ void __launch_bounds__(AT) attn_bwd_k_kernel(const float* __restrict__ go, const float* __restrict__ theta,
                                                         const float* __restrict__ phi, const float* __restrict__ g,
                                                         const float* __restrict__ lse, const float* __restrict__ delta,
-                                                        float* __restrict__ dphi, float* __restrict__ dg, int N, int M) {
+                                                        float* __restrict__ dphi, float* __restrict__ dg, int N, int M, int QS,
+                                                        int B) {
+  // blockIdx.z = query slice: the slice's sums go to partial buffers [QS][B][D or DV][M] (QS > 1) that
+  // attn_reduce_k_kernel adds in a fixed order; QS == 1 writes dphi / dg directly
   __shared__ float tq[KT][D];
   __shared__ float dq[KT][DV];
   __shared__ float ls[KT];
@@ -173,7 +176,10 @@ __global__ void __launch_bounds__(AT) attn_bwd_k_kernel(const float* __restrict_
   for (int v = 0; v < DV; ++v) { kg[v] = live ? gb[(int64_t)v * M + k] : 0.f; dkg[v] = 0.f; }
   const float* th = theta + (int64_t)b * D * N;
   const float* gob = go + (int64_t)b * DV * N;
-  for (int n0 = 0; n0 < N; n0 += KT) {
+  const int slice = blockIdx.z;
+  const int per = ((N + QS - 1) / QS + KT - 1) / KT * KT;
+  const int n_begin = slice * per, n_end = min(N, n_begin + per);
+  for (int n0 = n_begin; n0 < n_end; n0 += KT) {
     __syncthreads();
     for (int e = threadIdx.x; e < KT * D; e += AT) {
       const int q = e % KT, d = e / KT;
@@ -203,13 +209,33 @@ __global__ void __launch_bounds__(AT) attn_bwd_k_kernel(const float* __restrict_
     }
   }
   if (live) {
-    float* dp_ = dphi + (int64_t)b * D * M;
-    float* dg_ = dg + (int64_t)b * DV * M;
+    float* dp_ = dphi + ((int64_t)slice * B + b) * D * M;
+    float* dg_ = dg + ((int64_t)slice * B + b) * DV * M;
 #pragma unroll
     for (int d = 0; d < D; ++d) dp_[(int64_t)d * M + k] = dkp[d];
 #pragma unroll
     for (int v = 0; v < DV; ++v) dg_[(int64_t)v * M + k] = dkg[v];
   }
+}
+
+// out[i] = sum_s part[s][i]  (fixed order)
+__global__ void __launch_bounds__(AT) attn_reduce_k_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int QS) {
+  for (int64_t i = blockIdx.x * (int64_t)AT + threadIdx.x; i < n; i += gridDim.x * (int64_t)AT) {
+    float acc = 0.f;
+    for (int sidx = 0; sidx < QS; ++sidx) acc += part[sidx * n + i];
+    out[i] = acc;
+  }
+}
+
+// query slices for the key-owned kernel: enough workgroups to fill the chip
+static inline int attn_qsplit(int B, int N, int M) {
+  const int64_t base = (int64_t)((M + AT - 1) / AT) * B;
+  int qs = (int)((1024 + base - 1) / base);
+  const int maxqs = (N + KT - 1) / KT;
+  if (qs > maxqs) qs = maxqs;
+  if (qs > 16) qs = 16;
+  if (qs < 1) qs = 1;
+  return qs;
 }
 
 template <int D, int DV>
@@ -220,11 +246,22 @@ int launch_fwd(const float* theta, const float* phi, const float* g, float* o, f
 }
 template <int D, int DV>
 int launch_bwd(const float* go, const float* theta, const float* phi, const float* g, const float* o, const float* lse,
-               float* dtheta, float* dphi, float* dg, float* delta, int B, int N, int M, hipStream_t st) {
-  dim3 gq((N + AT - 1) / AT, B), gk((M + AT - 1) / AT, B);
+               float* dtheta, float* dphi, float* dg, float* ws, int B, int N, int M, hipStream_t st) {
+  const int QS = attn_qsplit(B, N, M);
+  float* delta = ws;
+  float* pphi = ws + (int64_t)B * N;
+  float* pg = pphi + (int64_t)QS * B * D * M;
+  dim3 gq((N + AT - 1) / AT, B), gk((M + AT - 1) / AT, B, QS);
   attn_delta_kernel<<<gq, AT, 0, st>>>(go, o, delta, DV, N);
   attn_bwd_q_kernel<D, DV><<<gq, AT, 0, st>>>(go, theta, phi, g, lse, delta, dtheta, N, M);
-  attn_bwd_k_kernel<D, DV><<<gk, AT, 0, st>>>(go, theta, phi, g, lse, delta, dphi, dg, N, M);
+  if (QS == 1) {
+    attn_bwd_k_kernel<D, DV><<<gk, AT, 0, st>>>(go, theta, phi, g, lse, delta, dphi, dg, N, M, 1, B);
+  } else {
+    attn_bwd_k_kernel<D, DV><<<gk, AT, 0, st>>>(go, theta, phi, g, lse, delta, pphi, pg, N, M, QS, B);
+    const int64_t n1 = (int64_t)B * D * M, n2 = (int64_t)B * DV * M;
+    attn_reduce_k_kernel<<<tg_ew_grid(n1, AT), AT, 0, st>>>(pphi, dphi, n1, QS);
+    attn_reduce_k_kernel<<<tg_ew_grid(n2, AT), AT, 0, st>>>(pg, dg, n2, QS);
+  }
   return tg_launch_status();
 }
 
@@ -242,6 +279,12 @@ extern "C" {
 
 int tg_attn_supported(int D, int DV) {
   return (D == 4 && DV == 16) || (D == 16 && DV == 64) || (D == 8 && DV == 32) || (D == 2 && DV == 8) || (D == 1 && DV == 4);
+}
+
+size_t tg_attn_bwd_workspace(int B, int D, int DV, int N, int M) {
+  if (B <= 0 || D <= 0 || DV <= 0 || N <= 0 || M <= 0) return 0;
+  const int QS = attn_qsplit(B, N, M);
+  return ((size_t)B * N + (size_t)QS * B * (D + DV) * M) * sizeof(float);
 }
 
 int tg_attn_fwd(const float* theta, const float* phi, const float* g, float* o, float* lse, int B, int D, int DV, int N, int M,

@@ -54,13 +54,13 @@ struct RedStats {
 __global__ void stats_stage2(const double* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
                              float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv,
                              int64_t* __restrict__ nbt, float momentum, float eps, int B, int C, int HW, int S) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt != nullptr) *nbt += 1;
-  if (c >= C) return;
+  const int c = blockIdx.x;                       // one wave per channel
   const double n = (double)B * HW;
   const double pivot = (double)x[(int64_t)c * HW];
   const double s1 = planes::gather(partial, c, S, 2, 0) / n;
   const double s2 = planes::gather(partial, c, S, 2, 1) / n;
+  if (threadIdx.x != 0) return;
+  if (c == 0 && nbt != nullptr) *nbt += 1;
   const double m = pivot + s1;
   double var = s2 - s1 * s1;
   if (var < 0.0) var = 0.0;
@@ -135,11 +135,11 @@ struct RedBwd {
 
 __global__ void bwd_stage2(const double* __restrict__ partial, float* __restrict__ ggamma, float* __restrict__ gbeta,
                            float* __restrict__ coef, int B, int C, int HW, int S, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;                       // one wave per channel
   const double n = (double)B * HW;
   const double sb = planes::gather(partial, c, S, 2, 0);
   const double sg = planes::gather(partial, c, S, 2, 1);
+  if (threadIdx.x != 0) return;
   gbeta[c] = (float)sb + (accumulate ? gbeta[c] : 0.f);
   ggamma[c] = (float)sg + (accumulate ? ggamma[c] : 0.f);
   coef[c * COEF + 0] = (float)(sb / n);
@@ -201,12 +201,12 @@ struct RedDbwd {
 __global__ void dbwd_stage2(const double* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ invstd,
                             const float* __restrict__ vgamma, float* __restrict__ adj_gamma, float* __restrict__ coef,
                             int B, int C, int HW, int S) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int c = blockIdx.x;                       // one wave per channel
   const double n = (double)B * HW;
   const double S1 = planes::gather(partial, c, S, 5, 0), S2 = planes::gather(partial, c, S, 5, 1);
   const double S3 = planes::gather(partial, c, S, 5, 2), S4 = planes::gather(partial, c, S, 5, 3);
   const double S5 = planes::gather(partial, c, S, 5, 4);
+  if (threadIdx.x != 0) return;
   const double r = (double)invstd[c], g = (double)gamma[c];
   const double vg = vgamma ? (double)vgamma[c] : 0.0;
   const double A = S5 - S1 * S3 / n - S2 * S4 / n;
@@ -281,7 +281,7 @@ int tg_bn_train_stats(const float* x, float* mean, float* invstd, float* running
   Parts p = split_ws(workspace, B, C, HW);
   RedStats red{x, C, HW, 0.f};
   planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x));
-  stats_stage2<<<chan_grid(C), 64, 0, st>>>(p.partial, x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, B, C, HW,
+  stats_stage2<<<C, 64, 0, st>>>(p.partial, x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, B, C, HW,
                                             planes::splits(B, C, HW));
   return tg_launch_status();
 }
@@ -313,7 +313,7 @@ int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const floa
   Parts p = split_ws(workspace, B, C, HW);
   RedBwd red{gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
   planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz));
-  bwd_stage2<<<chan_grid(C), 64, 0, st>>>(p.partial, ggamma, gbeta, p.coef, B, C, HW, planes::splits(B, C, HW), accumulate);
+  bwd_stage2<<<C, 64, 0, st>>>(p.partial, ggamma, gbeta, p.coef, B, C, HW, planes::splits(B, C, HW), accumulate);
   if (gx != nullptr) {
     BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, training};
     planes::launch_map(body, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx));
@@ -332,7 +332,7 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, cons
   RedDbwd red{v, gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
   const bool al = tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(v) && tg_aligned16(adj_gz) && tg_aligned16(adj_x);
   planes::launch_reduce(red, p.partial, B, C, HW, st, al);
-  dbwd_stage2<<<chan_grid(C), 64, 0, st>>>(p.partial, gamma, invstd, vgamma, adj_gamma, p.coef, B, C, HW,
+  dbwd_stage2<<<C, 64, 0, st>>>(p.partial, gamma, invstd, vgamma, adj_gamma, p.coef, B, C, HW,
                                            planes::splits(B, C, HW));
   DbwdBody body{v, gz, x, adj_gz, adj_x, mean, invstd, gamma, beta, vgamma, vbeta, p.coef, slope};
   planes::launch_map(body, B, C, HW, st, al);

@@ -101,11 +101,13 @@ static inline void launch_reduce(Red red, double* partial, int B, int C, int HW,
   reduce_stage1<Red><<<grid, BLOCK, 0, st>>>(red, partial, B, C, HW, S, (big(HW) && aligned) ? 1 : 0);
 }
 
-// helper for stage 2 kernels: sum the S partials of value k of channel c
+// helper for stage 2 kernels (ONE WAVE PER CHANNEL, blockDim = 64): sum the S partials of value k of
+// channel c.  Lanes stride over S and combine by wavefront shuffles; result in every lane.  (A serial
+// loop of S dependent loads per channel made these tiny kernels cost ~9 us each.)
 __device__ __forceinline__ double gather(const double* __restrict__ partial, int c, int S, int K, int k) {
   double r = 0.0;
-  for (int s = 0; s < S; ++s) r += partial[((int64_t)c * S + s) * K + k];
-  return r;
+  for (int s = threadIdx.x & 63; s < S; s += 64) r += partial[((int64_t)c * S + s) * K + k];
+  return wave_sum_d(r);
 }
 
 }  // namespace planes

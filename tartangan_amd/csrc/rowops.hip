@@ -27,8 +27,9 @@ struct RedChan {
 };
 
 __global__ void chan_stage2(const double* __restrict__ partial, float* __restrict__ out, int C, int S, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) out[c] = (float)planes::gather(partial, c, S, 1, 0) + (accumulate ? out[c] : 0.f);
+  const int c = blockIdx.x;                       // one wave per channel
+  const double r = planes::gather(partial, c, S, 1, 0);
+  if (threadIdx.x == 0) out[c] = (float)r + (accumulate ? out[c] : 0.f);
 }
 
 struct BcastBody {
@@ -136,7 +137,7 @@ int tg_channel_sum(const float* x, float* out, float* workspace, int B, int C, i
   hipStream_t st = tg_stream(stream);
   double* partial = reinterpret_cast<double*>(workspace);
   planes::launch_reduce(RedChan{x}, partial, B, C, HW, st, tg_aligned16(x));
-  chan_stage2<<<(C + 63) / 64, 64, 0, st>>>(partial, out, C, planes::splits(B, C, HW), accumulate);
+  chan_stage2<<<C, 64, 0, st>>>(partial, out, C, planes::splits(B, C, HW), accumulate);
   return tg_launch_status();
 }
 

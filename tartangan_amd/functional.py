@@ -829,7 +829,8 @@ class _AttnCore(Function):
         B, D, N = theta.shape
         DV, M = g.shape[1], g.shape[2]
         dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
-        K().attn_bwd(go, theta, phi, g, o, lse, dtheta, dphi, dg, _ws(go, B * N * 4), B, D, DV, N, M)
+        K().attn_bwd(go, theta, phi, g, o, lse, dtheta, dphi, dg, _ws(go, K().attn_bwd_workspace(B, D, DV, N, M)),
+                     B, D, DV, N, M)
         return dtheta, dphi, dg
 
 

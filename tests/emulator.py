@@ -272,6 +272,9 @@ class Emulator:
     def attn_supported(self, D, DV):
         return int((D, DV) in ((1, 4), (2, 8), (4, 16), (8, 32), (16, 64)))
 
+    def attn_bwd_workspace(self, B, D, DV, N, M):
+        return 16
+
     def attn_fwd(self, theta, phi, g, o, lse, B, D, DV, N, M):
         s = torch.bmm(theta.view(B, D, N).transpose(1, 2), phi.view(B, D, M))
         lse.view(B, N).copy_(torch.logsumexp(s, -1))

@@ -255,7 +255,7 @@ def test_fused_attention(K, dims):
     run_both(K, 'attn_fwd', [theta, phi, g, o, lse, B, D, DV, N, M], [3, 4], tol=6e-6)   # online softmax + v_exp_f32
     E.attn_fwd(theta, phi, g, o, lse, B, D, DV, N, M)
     go = rnd(B, DV, N, seed=3)
-    ws = workspace(B * N * 4)
+    ws = workspace(K.attn_bwd_workspace(B, D, DV, N, M))
     run_both(K, 'attn_bwd', [go, theta, phi, g, o, lse, torch.zeros(B, D, N), torch.zeros(B, D, M), torch.zeros(B, DV, M),
                              ws, B, D, DV, N, M], [6, 7, 8], tol=2e-5)
 
