@@ -326,30 +326,29 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
       ps.load(x, s, s.Cin, ci0 + CK, tc, vec_x);
       ws.load(w, s.Cin, s.Cout, ci0 + CK, co0, vec_w);
     }
-    // skip all-zero k-groups of a ragged last chunk (wave-uniform)
-    const int kgroups = (min(CK, s.Cin - ci0) + KG - 1) / KG;
+    // No per-k-group branch here: channels past Cin are zero in LDS (a ragged last chunk just multiplies
+    // zeros).  A wave-uniform `if` around the MFMA block made hipcc shuttle all accumulators between
+    // VGPRs and AGPRs on both sides of it (64 v_accvgpr moves + s_nop 15 per 18 MFMAs).
 #pragma unroll
     for (int gi = 0; gi < NG / GSTEP; ++gi) {
       const int g = gi * GSTEP;               // + g0 (in the lane bases)
-      if (g + g0 < kgroups) {
 #pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
-          const int kh = tap / KS, kw = tap % KS;
-          float a[MT], b[NT];
+      for (int tap = 0; tap < KK; ++tap) {
+        const int kh = tap / KS, kw = tap % KS;
+        float a[MT], b[NT];
 #pragma unroll
-          for (int m = 0; m < MT; ++m) a[m] = wl[lane_a + ((g * KG) * KK + tap) * CTS + m * MF];
+        for (int m = 0; m < MT; ++m) a[m] = wl[lane_a + ((g * KG) * KK + tap) * CTS + m * MF];
 #pragma unroll
-          for (int n = 0; n < NT; ++n) b[n] = pl[lane_b[n] + (g * KG) * P::CIS + kh * P::PWS + kw];
+        for (int n = 0; n < NT; ++n) b[n] = pl[lane_b[n] + (g * KG) * P::CIS + kh * P::PWS + kw];
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              if constexpr (MF == 32)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
-              else
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
-            }
-        }
+          for (int n = 0; n < NT; ++n) {
+            if constexpr (MF == 32)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            else
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+          }
       }
     }
   }

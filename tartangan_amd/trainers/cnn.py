@@ -144,26 +144,47 @@ class CNNTrainer(Trainer):
         if iqn is not None:
             iqn.tau_source = lambda rows, q: self.rng_feed.draw('tau', rows, q)
 
+    def _capture(self, imgs):
+        feed = self.rng_feed
+        feed.mode = 'serve'
+        feed.cursor = 0
+        self._static_imgs = imgs.clone()
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # with a process group alive, its watchdog thread polls events; only this thread's calls matter here
+        kw = dict(pool=pool)
+        if self.data_parallel is not None and self.data_parallel.world > 1:
+            kw['capture_error_mode'] = 'thread_local'
+        with torch.cuda.graph(g1, **kw):
+            self._out_d = self._d_phase(self._static_imgs)
+        with torch.cuda.graph(g2, **kw):
+            self.optimizer_d.apply()
+            self._out_g = self._g_phase(len(imgs))
+        with torch.cuda.graph(g3, **kw):
+            self.optimizer_g.apply()
+            self.update_target_generator()
+        self._graphs = (g1, g2, g3)
+        feed.cursor = 0
+
     def _train_batch_graphed(self, imgs):
         feed = self.rng_feed
         if self._graphs is None and not feed.plan:
             return self._train_batch_eager(imgs)               # call 1: eager, records the RNG plan
         feed.refill()
         if self._graphs is None:                               # call 2: capture (nothing executes yet)
-            feed.mode = 'serve'
-            self._static_imgs = imgs.clone()
-            pool = torch.cuda.graph_pool_handle()
-            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, pool=pool):
-                self._out_d = self._d_phase(self._static_imgs)
-            with torch.cuda.graph(g2, pool=pool):
-                self.optimizer_d.apply()
-                self._out_g = self._g_phase(len(imgs))
-            with torch.cuda.graph(g3, pool=pool):
-                self.optimizer_g.apply()
-                self.update_target_generator()
-            self._graphs = (g1, g2, g3)
-            feed.cursor = 0
+            try:
+                self._capture(imgs)
+            except Exception as exc:                           # e.g. a collective library that refuses capture
+                import warnings
+                warnings.warn(f'HIP-graph capture failed ({exc!r}); continuing in eager mode')
+                self._graph_requested = False
+                self._graphs = None
+                feed.mode, feed.cursor = 'serve', 0
+                try:
+                    return self._train_batch_eager(imgs)       # consumes the values refill() just drew
+                finally:
+                    feed.mode = 'off'
         g1, g2, g3 = self._graphs
         self._static_imgs.copy_(imgs, non_blocking=True)
         self.optimizer_d.advance()
