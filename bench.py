@@ -45,6 +45,8 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-kernel-timing', action='store_true')
     p.add_argument('--cpu-batch', type=int, default=16)
+    p.add_argument('--backend', default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the DP code path)')
+    p.add_argument('--share-gpu', action='store_true', help='rehearsal only: every rank uses cuda:0')
     return p.parse_args()
 
 
@@ -74,7 +76,7 @@ class KernelTimer:
     def __enter__(self):
         for name in ('conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad', 'bn_train_stats', 'bn_act_fwd', 'bn_act_bwd',
                      'bn_act_dbwd', 'gemm', 'softmax_fwd', 'softmax_bwd', 'softmax_dbwd', 'up2x', 'pool2',
-                     'bilinear_half_fwd', 'bilinear_half_bwd', 'add', 'channel_sum', 'adam_step', 'ema', 'attn_fwd', 'attn_bwd',
+                     'bilinear_half_fwd', 'bilinear_half_bwd', 'add', 'channel_sum', 'adam_step', 'ema', 'attn_fwd', 'attn_bwd', 'bn_train_fwd',
                      'maxpool2_fwd', 'maxpool2_bwd', 'scale_add_dev', 'dot', 'scale_dev', 'mul', 'lrelu_bwd', 'tanh_fwd', 'tanh_bwd',
                      'row_sum', 'row_bcast', 'bce_logits', 'sumsq', 'fill', 'scale', 'channel_bcast'):
             fn = getattr(self.K, name)
@@ -141,10 +143,15 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(a.backend)
 
     from tartangan_amd import backend
     K = backend.get()                          # fails loudly without the HIP library

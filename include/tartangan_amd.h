@@ -78,6 +78,13 @@ int tg_bn_train_stats(const float* x, float* mean, float* invstd,
                       float* running_mean /*nullable*/, float* running_var /*nullable*/,
                       int64_t* num_batches_tracked /*nullable*/,
                       float momentum, float eps, float* workspace, int B, int C, int HW, void* stream);
+/* training forward in one call: tg_bn_train_stats followed by tg_bn_act_fwd (one kernel when a channel
+ * has <= 16384 elements)                                                                              */
+int tg_bn_train_fwd(const float* x, float* mean, float* invstd,
+                    float* running_mean /*nullable*/, float* running_var /*nullable*/,
+                    int64_t* num_batches_tracked /*nullable*/, const float* gamma, const float* beta,
+                    float slope, float momentum, float eps, float* z, float* workspace,
+                    int B, int C, int HW, void* stream);
 /* eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps) */
 int tg_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd,
                      float eps, int C, void* stream);

@@ -261,6 +261,127 @@ struct DbwdBody {
 
 static inline int chan_grid(int C) { return (C + 63) / 64; }
 
+// ------------------------------------------------------------------ small tensors: one workgroup per channel
+// When a channel has <= SMALL_N elements (4x4 ... 16x16 layers at batch 64) the three-launch pipeline above is
+// pure launch latency (~20 us for a few hundred KB).  One kernel, one workgroup per channel: reduce, then apply
+// (the second read hits L2).  Same arithmetic as the large path (fp32 per-thread partials, fp64 combine).
+constexpr int SMALL_N = 16384;
+static inline bool small_case(int B, int C, int HW) { return (int64_t)B * HW <= SMALL_N && C >= 8; }
+
+template <class F>
+__device__ __forceinline__ void chan_each(int B, int C, int HW, int c, F f) {
+  const int n = B * HW;
+  for (int e = threadIdx.x; e < n; e += BLOCK) {
+    const int b = e / HW, p = e - b * HW;
+    f(((int64_t)b * C + c) * HW + p);
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ invstd,
+                                                             float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                             float momentum, float eps, float* __restrict__ z, int B, int C, int HW) {
+  __shared__ double scratch[32];
+  const int c = blockIdx.x;
+  const float pivot = x[(int64_t)c * HW];
+  float a0 = 0.f, a1 = 0.f;
+  chan_each(B, C, HW, c, [&](int64_t off) { const float d = x[off] - pivot; a0 += d; a1 += d * d; });
+  const double n = (double)B * HW;
+  const double s1 = block_sum_d((double)a0, scratch) / n;
+  const double s2 = block_sum_d((double)a1, scratch) / n;
+  const double m = (double)pivot + s1;
+  double var = s2 - s1 * s1;
+  if (var < 0.0) var = 0.0;
+  const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    mean[c] = mf;
+    invstd[c] = rf;
+    if (rm != nullptr) {
+      const double unbiased = n > 1.0 ? var * (n / (n - 1.0)) : var;
+      rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * m);
+      rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
+    }
+    if (c == 0 && nbt != nullptr) *nbt += 1;
+  }
+  const float a = gamma[c] * rf, b = beta[c] - mf * a;
+  chan_each(B, C, HW, c, [&](int64_t off) {
+    const float y = bn_y(x[off], a, b);
+    z[off] = y >= 0.f ? y : y * slope;
+  });
+}
+
+__global__ void __launch_bounds__(BLOCK) bn_small_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ x,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                             int training, float* __restrict__ gx, float* __restrict__ ggamma,
+                                                             float* __restrict__ gbeta, int B, int C, int HW, int accumulate) {
+  __shared__ double scratch[32];
+  const int c = blockIdx.x;
+  const float r = invstd[c], mu = mean[c], a = gamma[c] * r, b = beta[c] - mu * a;
+  float a0 = 0.f, a1 = 0.f;
+  chan_each(B, C, HW, c, [&](int64_t off) {
+    const float xv = x[off];
+    const float gyh = bn_y(xv, a, b) >= 0.f ? gz[off] : gz[off] * slope;
+    a0 += gyh;
+    a1 += gyh * ((xv - mu) * r);
+  });
+  const double n = (double)B * HW;
+  const double sb = block_sum_d((double)a0, scratch), sg = block_sum_d((double)a1, scratch);
+  if (threadIdx.x == 0) {
+    gbeta[c] = (float)sb + (accumulate ? gbeta[c] : 0.f);
+    ggamma[c] = (float)sg + (accumulate ? ggamma[c] : 0.f);
+  }
+  if (gx == nullptr) return;
+  const float k1 = (float)(sb / n), k2 = (float)(sg / n);
+  chan_each(B, C, HW, c, [&](int64_t off) {
+    const float xv = x[off];
+    const float gyh = bn_y(xv, a, b) >= 0.f ? gz[off] : gz[off] * slope;
+    gx[off] = training ? a * (gyh - k1 - ((xv - mu) * r) * k2) : a * gyh;
+  });
+}
+
+__global__ void __launch_bounds__(BLOCK) bn_small_dbwd_kernel(const float* __restrict__ v, const float* __restrict__ vgamma,
+                                                              const float* __restrict__ vbeta, const float* __restrict__ gz,
+                                                              const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float slope, float* __restrict__ adj_gz,
+                                                              float* __restrict__ adj_x, float* __restrict__ adj_gamma, int B, int C, int HW) {
+  __shared__ double scratch[32];
+  const int c = blockIdx.x;
+  const float r = invstd[c], mu = mean[c], gr = gamma[c] * r, b = beta[c] - mu * gr;
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  chan_each(B, C, HW, c, [&](int64_t off) {
+    const float xv = x[off], vv = v[off];
+    const float gyh = bn_y(xv, gr, b) >= 0.f ? gz[off] : gz[off] * slope;
+    const float xh = (xv - mu) * r;
+    acc[0] += vv; acc[1] += vv * xh; acc[2] += gyh; acc[3] += gyh * xh; acc[4] += vv * gyh;
+  });
+  const double n = (double)B * HW;
+  const double S1 = block_sum_d((double)acc[0], scratch), S2 = block_sum_d((double)acc[1], scratch);
+  const double S3 = block_sum_d((double)acc[2], scratch), S4 = block_sum_d((double)acc[3], scratch);
+  const double S5 = block_sum_d((double)acc[4], scratch);
+  const double rd = (double)r, g = (double)gamma[c];
+  const double vg = vgamma ? (double)vgamma[c] : 0.0;
+  const double A = S5 - S1 * S3 / n - S2 * S4 / n;
+  const double cgd = S4 / n, cvd = S2 / n;
+  const float k0 = (float)(S1 / n), k1 = (float)(S2 / n), cg = (float)cgd, cv = (float)cvd;
+  const float qm = (float)(-g * rd * (cgd * S1 / n + cvd * S3 / n) + vg * S3 / n);
+  const float qx = (float)(-g * rd * (cgd * S2 / n + cvd * S4 / n) + vg * S4 / n);
+  const float k6 = (float)(g * A * rd * rd / n);
+  const float vgf = (float)vg, vbf = vbeta ? vbeta[c] : 0.f;
+  if (threadIdx.x == 0) adj_gamma[c] = (float)(rd * A);
+  chan_each(B, C, HW, c, [&](int64_t off) {
+    const float xv = x[off], vv = v[off];
+    const float s = bn_y(xv, gr, b) >= 0.f ? 1.f : slope;
+    const float gyh = gz[off] * s;
+    const float xh = (xv - mu) * r;
+    const float pv = vv - k0 - xh * k1;
+    adj_gz[off] = (gr * pv + vgf * xh + vbf) * s;
+    const float q = -gr * (cg * vv + cv * gyh) + vgf * gyh;
+    adj_x[off] = r * (q - qm - xh * qx) - k6 * xh;
+  });
+}
+
 }  // namespace
 
 extern "C" {
@@ -284,6 +405,24 @@ int tg_bn_train_stats(const float* x, float* mean, float* invstd, float* running
   stats_stage2<<<C, 64, 0, st>>>(p.partial, x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, B, C, HW,
                                             planes::splits(B, C, HW));
   return tg_launch_status();
+}
+
+int tg_bn_train_fwd(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, const float* gamma, const float* beta, float slope, float momentum, float eps,
+                    float* z, float* workspace, int B, int C, int HW, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta); TG_CHECK_PTR(z);
+  TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  if ((running_mean == nullptr) != (running_var == nullptr)) return TG_EINVAL;
+  if (small_case(B, C, HW)) {
+    bn_small_fwd_kernel<<<C, BLOCK, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
+                                                            gamma, beta, slope, momentum, eps, z, B, C, HW);
+    return tg_launch_status();
+  }
+  if (int rc = tg_bn_train_stats(x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, workspace, B, C,
+                                 HW, stream))
+    return rc;
+  return tg_bn_act_fwd(x, mean, invstd, gamma, beta, slope, z, B, C, HW, stream);
 }
 
 int tg_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, float eps, int C,
@@ -310,6 +449,11 @@ int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const floa
   TG_CHECK_PTR(ggamma); TG_CHECK_PTR(gbeta); TG_CHECK_PTR(workspace);
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   hipStream_t st = tg_stream(stream);
+  if (small_case(B, C, HW)) {
+    bn_small_bwd_kernel<<<C, BLOCK, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
+                                             accumulate);
+    return tg_launch_status();
+  }
   Parts p = split_ws(workspace, B, C, HW);
   RedBwd red{gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
   planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz));
@@ -328,6 +472,11 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, cons
   TG_CHECK_PTR(beta); TG_CHECK_PTR(adj_gz); TG_CHECK_PTR(adj_x); TG_CHECK_PTR(adj_gamma); TG_CHECK_PTR(workspace);
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   hipStream_t st = tg_stream(stream);
+  if (small_case(B, C, HW)) {
+    bn_small_dbwd_kernel<<<C, BLOCK, 0, st>>>(v, vgamma, vbeta, gz, x, mean, invstd, gamma, beta, slope, adj_gz, adj_x, adj_gamma,
+                                              B, C, HW);
+    return tg_launch_status();
+  }
   Parts p = split_ws(workspace, B, C, HW);
   RedDbwd red{v, gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
   const bool al = tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(v) && tg_aligned16(adj_gz) && tg_aligned16(adj_x);

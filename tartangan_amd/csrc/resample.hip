@@ -140,6 +140,53 @@ __global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_kernel(const float
   }
 }
 
+// Plane-per-workgroup variant: the per-axis candidate windows / weights are computed ONCE per workgroup into LDS
+// (H + W entries instead of 8 index evaluations per element) and the gy plane is read from LDS.
+constexpr int BL_MAX_OUT = 8192;     // OH*OW floats of gy staged in LDS (32 KB)
+struct AxisEntry { int lo; float w[4]; };
+__global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_plane_kernel(const float* __restrict__ gy, float* __restrict__ gx, int BC,
+                                                                           int H, int W, int OH, int OW, float sh, float sw) {
+  __shared__ float g[BL_MAX_OUT];
+  __shared__ AxisEntry rows[128], cols[128];
+  for (int i = threadIdx.x; i < H + W; i += RS_BLOCK) {
+    const bool is_row = i < H;
+    const int in = is_row ? i : i - H;
+    const float sc = is_row ? sh : sw;
+    const int in_size = is_row ? H : W, out_size = is_row ? OH : OW;
+    int lo = sc > 0.f ? (int)((float)(in - 1) / sc) - 1 : 0;
+    lo = lo < 0 ? 0 : lo;
+    AxisEntry e;
+    e.lo = lo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e.w[u] = (lo + u < out_size) ? axis_weight(lo + u, in, sc, in_size) : 0.f;
+    if (is_row) rows[in] = e; else cols[in] = e;
+  }
+  const int nout = OH * OW, nin = H * W;
+  for (int plane = blockIdx.x; plane < BC; plane += gridDim.x) {
+    __syncthreads();
+    const float* gp = gy + (int64_t)plane * nout;
+    for (int i = threadIdx.x; i < nout; i += RS_BLOCK) g[i] = gp[i];
+    __syncthreads();
+    float* xp = gx + (int64_t)plane * nin;
+    for (int i = threadIdx.x; i < nin; i += RS_BLOCK) {
+      const int h = i / W, w = i - h * W;
+      const AxisEntry r = rows[h], c = cols[w];
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r.w[u] == 0.f) continue;
+        const float* grow = g + (r.lo + u) * OW + c.lo;
+        float racc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (c.w[t] != 0.f) racc += c.w[t] * grow[t];
+        acc += r.w[u] * racc;
+      }
+      xp[i] = acc;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ 2x2 max pool
 __global__ void __launch_bounds__(RS_BLOCK) maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 uint8_t* __restrict__ idx, int64_t nout, int H, int W) {
@@ -238,6 +285,12 @@ int tg_bilinear_half_bwd(const float* gy, float* gx, int BC, int H, int W, void*
   if (H < 2 || W < 2) return TG_EUNSUPPORTED;
   const int OH = H / 2, OW = W / 2;
   const int64_t nin = (int64_t)BC * H * W;
+  if (H <= 128 && W <= 128 && OH * OW <= BL_MAX_OUT && H * W >= 256) {
+    const int grid = BC < 2048 ? BC : 2048;
+    bilinear_half_bwd_plane_kernel<<<grid, RS_BLOCK, 0, tg_stream(stream)>>>(gy, gx, BC, H, W, OH, OW, ac_scale(H, OH),
+                                                                             ac_scale(W, OW));
+    return tg_launch_status();
+  }
   bilinear_half_bwd_kernel<<<tg_ew_grid(nin, RS_BLOCK), RS_BLOCK, 0, tg_stream(stream)>>>(gy, gx, nin, H, W, OH, OW,
                                                                                          ac_scale(H, OH), ac_scale(W, OW));
   return tg_launch_status();

@@ -250,14 +250,14 @@ class _BNAct(Function):
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         mean, invstd = x.new_empty(C), x.new_empty(C)
+        z = torch.empty_like(x)
         if training:
             ws = _ws(x, K().bn_workspace(B, C, hw))
-            K().bn_train_stats(x, mean, invstd, running_mean, running_var, num_batches_tracked,
-                               float(momentum), float(eps), ws, B, C, hw)
+            K().bn_train_fwd(x, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta,
+                             float(slope), float(momentum), float(eps), z, ws, B, C, hw)
         else:
             K().bn_eval_stats(running_mean, running_var, mean, invstd, float(eps), C)
-        z = torch.empty_like(x)
-        K().bn_act_fwd(x, mean, invstd, gamma, beta, float(slope), z, B, C, hw)
+            K().bn_act_fwd(x, mean, invstd, gamma, beta, float(slope), z, B, C, hw)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.training, ctx.slope = bool(training), float(slope)
         return z

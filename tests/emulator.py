@@ -83,6 +83,10 @@ class Emulator:
             rv.mul_(1 - momentum).add_(momentum * var * (n / max(n - 1, 1)))
         return 0
 
+    def bn_train_fwd(self, x, mean, invstd, rm, rv, nbt, gamma, beta, slope, momentum, eps, z, ws, B, C, HW):
+        self.bn_train_stats(x, mean, invstd, rm, rv, nbt, momentum, eps, ws, B, C, HW)
+        return self.bn_act_fwd(x, mean, invstd, gamma, beta, slope, z, B, C, HW)
+
     def bn_eval_stats(self, rm, rv, mean, invstd, eps, C):
         mean.copy_(rm)
         invstd.copy_(1 / torch.sqrt(rv + eps))

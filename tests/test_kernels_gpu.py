@@ -117,7 +117,8 @@ def test_conv_rejects_unsupported(K):
         K.conv2d_fwd(x, torch.zeros(4, 4, 5, 5).cuda(), None, torch.zeros(1, 4, 8, 8).cuda(), 1, 4, 4, 8, 8, 5)
 
 
-BN_SHAPES = [(4, 16, 64 * 64), (8, 128, 16), (3, 3, 32 * 32), (2, 32, 128 * 128), (5, 100, 8 * 8), (64, 128, 1), (2, 7, 12 * 10)]
+BN_SHAPES = [(4, 16, 64 * 64), (8, 128, 16), (3, 3, 32 * 32), (2, 32, 128 * 128), (5, 100, 8 * 8), (64, 128, 1), (2, 7, 12 * 10),
+             (64, 128, 64), (64, 128, 256), (16, 64, 1024), (64, 128, 16)]
 
 
 @pytest.mark.parametrize('shape', BN_SHAPES)
@@ -130,6 +131,8 @@ def test_batchnorm_all_passes(K, shape):
     mean, invstd = torch.zeros(C), torch.zeros(C)
     nbt = torch.tensor(41, dtype=torch.int64)
     run_both(K, 'bn_train_stats', [x, mean, invstd, rm, rv, nbt, 0.1, 1e-5, ws, B, C, HW], [1, 2, 3, 4, 5], tol=1e-5)
+    run_both(K, 'bn_train_fwd', [x, torch.zeros(C), torch.zeros(C), rm, rv, nbt, gamma, beta, 0.2, 0.1, 1e-5,
+                                 torch.zeros(B, C, HW), ws, B, C, HW], [1, 2, 3, 4, 5, 11], tol=1e-5)
     E.bn_train_stats(x, mean, invstd, None, None, None, 0.1, 1e-5, None, B, C, HW)
     run_both(K, 'bn_eval_stats', [rm, rv, torch.zeros(C), torch.zeros(C), 1e-5, C], [2, 3], tol=1e-6)
     for slope in (0.2, 1.0):
