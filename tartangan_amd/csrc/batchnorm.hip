@@ -268,27 +268,54 @@ static inline int chan_grid(int C) { return (C + 63) / 64; }
 constexpr int SMALL_N = 16384;
 static inline bool small_case(int B, int C, int HW) { return (int64_t)B * HW <= SMALL_N && C >= 8; }
 
-template <class F>
-__device__ __forceinline__ void chan_each(int B, int C, int HW, int c, F f) {
-  const int n = B * HW;
-  for (int e = threadIdx.x; e < n; e += BLOCK) {
-    const int b = e / HW, p = e - b * HW;
-    f(((int64_t)b * C + c) * HW + p);
+// 1024 threads per channel, <= 16 elements per thread held in registers between the reduce and the apply pass:
+// every global load of a thread is issued up front (independent), nothing is read twice.
+constexpr int SB = 1024, SPER = SMALL_N / SB;
+
+struct SmallIdx {
+  int64_t off[SPER];
+  bool ok[SPER];
+  __device__ __forceinline__ SmallIdx(int B, int C, int HW, int c) {
+    const int n = B * HW;
+#pragma unroll
+    for (int i = 0; i < SPER; ++i) {
+      const int e = threadIdx.x + i * SB;
+      const int b = e / HW, p = e - b * HW;
+      ok[i] = e < n;
+      off[i] = ((int64_t)b * C + c) * HW + p;
+    }
   }
+};
+
+__device__ __forceinline__ double block_sum_d1024(double v, double* scratch) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  v = wave_sum_d(v);
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < SB / 64; ++i) r += scratch[i];
+  return r;
 }
 
-__global__ void __launch_bounds__(BLOCK) bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ invstd,
-                                                             float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
-                                                             float momentum, float eps, float* __restrict__ z, int B, int C, int HW) {
+__global__ void __launch_bounds__(SB) bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                          float momentum, float eps, float* __restrict__ z, int B, int C, int HW) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
+  const SmallIdx ix(B, C, HW, c);
   const float pivot = x[(int64_t)c * HW];
+  float xv[SPER];
+#pragma unroll
+  for (int i = 0; i < SPER; ++i) xv[i] = ix.ok[i] ? x[ix.off[i]] : pivot;
   float a0 = 0.f, a1 = 0.f;
-  chan_each(B, C, HW, c, [&](int64_t off) { const float d = x[off] - pivot; a0 += d; a1 += d * d; });
+#pragma unroll
+  for (int i = 0; i < SPER; ++i) { const float d = xv[i] - pivot; a0 += d; a1 += d * d; }
   const double n = (double)B * HW;
-  const double s1 = block_sum_d((double)a0, scratch) / n;
-  const double s2 = block_sum_d((double)a1, scratch) / n;
+  const double s1 = block_sum_d1024((double)a0, scratch) / n;
+  const double s2 = block_sum_d1024((double)a1, scratch) / n;
   const double m = (double)pivot + s1;
   double var = s2 - s1 * s1;
   if (var < 0.0) var = 0.0;
@@ -304,62 +331,76 @@ __global__ void __launch_bounds__(BLOCK) bn_small_fwd_kernel(const float* __rest
     if (c == 0 && nbt != nullptr) *nbt += 1;
   }
   const float a = gamma[c] * rf, b = beta[c] - mf * a;
-  chan_each(B, C, HW, c, [&](int64_t off) {
-    const float y = bn_y(x[off], a, b);
-    z[off] = y >= 0.f ? y : y * slope;
-  });
+#pragma unroll
+  for (int i = 0; i < SPER; ++i)
+    if (ix.ok[i]) {
+      const float y = bn_y(xv[i], a, b);
+      z[ix.off[i]] = y >= 0.f ? y : y * slope;
+    }
 }
 
-__global__ void __launch_bounds__(BLOCK) bn_small_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ x,
-                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
-                                                             int training, float* __restrict__ gx, float* __restrict__ ggamma,
-                                                             float* __restrict__ gbeta, int B, int C, int HW, int accumulate) {
+__global__ void __launch_bounds__(SB) bn_small_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ x,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                          int training, float* __restrict__ gx, float* __restrict__ ggamma,
+                                                          float* __restrict__ gbeta, int B, int C, int HW, int accumulate) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
+  const SmallIdx ix(B, C, HW, c);
   const float r = invstd[c], mu = mean[c], a = gamma[c] * r, b = beta[c] - mu * a;
+  float gyh[SPER], xh[SPER];
+#pragma unroll
+  for (int i = 0; i < SPER; ++i) {
+    const float xv = ix.ok[i] ? x[ix.off[i]] : mu;
+    const float g = ix.ok[i] ? gz[ix.off[i]] : 0.f;
+    gyh[i] = bn_y(xv, a, b) >= 0.f ? g : g * slope;
+    xh[i] = (xv - mu) * r;
+  }
   float a0 = 0.f, a1 = 0.f;
-  chan_each(B, C, HW, c, [&](int64_t off) {
-    const float xv = x[off];
-    const float gyh = bn_y(xv, a, b) >= 0.f ? gz[off] : gz[off] * slope;
-    a0 += gyh;
-    a1 += gyh * ((xv - mu) * r);
-  });
+#pragma unroll
+  for (int i = 0; i < SPER; ++i) { a0 += gyh[i]; a1 += gyh[i] * xh[i]; }
   const double n = (double)B * HW;
-  const double sb = block_sum_d((double)a0, scratch), sg = block_sum_d((double)a1, scratch);
+  const double sb = block_sum_d1024((double)a0, scratch), sg = block_sum_d1024((double)a1, scratch);
   if (threadIdx.x == 0) {
     gbeta[c] = (float)sb + (accumulate ? gbeta[c] : 0.f);
     ggamma[c] = (float)sg + (accumulate ? ggamma[c] : 0.f);
   }
   if (gx == nullptr) return;
   const float k1 = (float)(sb / n), k2 = (float)(sg / n);
-  chan_each(B, C, HW, c, [&](int64_t off) {
-    const float xv = x[off];
-    const float gyh = bn_y(xv, a, b) >= 0.f ? gz[off] : gz[off] * slope;
-    gx[off] = training ? a * (gyh - k1 - ((xv - mu) * r) * k2) : a * gyh;
-  });
+#pragma unroll
+  for (int i = 0; i < SPER; ++i)
+    if (ix.ok[i]) gx[ix.off[i]] = training ? a * (gyh[i] - k1 - xh[i] * k2) : a * gyh[i];
 }
 
-__global__ void __launch_bounds__(BLOCK) bn_small_dbwd_kernel(const float* __restrict__ v, const float* __restrict__ vgamma,
-                                                              const float* __restrict__ vbeta, const float* __restrict__ gz,
-                                                              const float* __restrict__ x, const float* __restrict__ mean,
-                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float slope, float* __restrict__ adj_gz,
-                                                              float* __restrict__ adj_x, float* __restrict__ adj_gamma, int B, int C, int HW) {
+__global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restrict__ v, const float* __restrict__ vgamma,
+                                                           const float* __restrict__ vbeta, const float* __restrict__ gz,
+                                                           const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float slope, float* __restrict__ adj_gz,
+                                                           float* __restrict__ adj_x, float* __restrict__ adj_gamma, int B, int C, int HW) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
+  const SmallIdx ix(B, C, HW, c);
   const float r = invstd[c], mu = mean[c], gr = gamma[c] * r, b = beta[c] - mu * gr;
+  float vv[SPER], gyh[SPER], xh[SPER], sl[SPER];
+#pragma unroll
+  for (int i = 0; i < SPER; ++i) {
+    const float xv = ix.ok[i] ? x[ix.off[i]] : mu;
+    vv[i] = ix.ok[i] ? v[ix.off[i]] : 0.f;
+    const float g = ix.ok[i] ? gz[ix.off[i]] : 0.f;
+    sl[i] = bn_y(xv, gr, b) >= 0.f ? 1.f : slope;
+    gyh[i] = g * sl[i];
+    xh[i] = (xv - mu) * r;
+  }
   float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  chan_each(B, C, HW, c, [&](int64_t off) {
-    const float xv = x[off], vv = v[off];
-    const float gyh = bn_y(xv, gr, b) >= 0.f ? gz[off] : gz[off] * slope;
-    const float xh = (xv - mu) * r;
-    acc[0] += vv; acc[1] += vv * xh; acc[2] += gyh; acc[3] += gyh * xh; acc[4] += vv * gyh;
-  });
+#pragma unroll
+  for (int i = 0; i < SPER; ++i) {
+    acc[0] += vv[i]; acc[1] += vv[i] * xh[i]; acc[2] += gyh[i]; acc[3] += gyh[i] * xh[i]; acc[4] += vv[i] * gyh[i];
+  }
   const double n = (double)B * HW;
-  const double S1 = block_sum_d((double)acc[0], scratch), S2 = block_sum_d((double)acc[1], scratch);
-  const double S3 = block_sum_d((double)acc[2], scratch), S4 = block_sum_d((double)acc[3], scratch);
-  const double S5 = block_sum_d((double)acc[4], scratch);
+  const double S1 = block_sum_d1024((double)acc[0], scratch), S2 = block_sum_d1024((double)acc[1], scratch);
+  const double S3 = block_sum_d1024((double)acc[2], scratch), S4 = block_sum_d1024((double)acc[3], scratch);
+  const double S5 = block_sum_d1024((double)acc[4], scratch);
   const double rd = (double)r, g = (double)gamma[c];
   const double vg = vgamma ? (double)vgamma[c] : 0.0;
   const double A = S5 - S1 * S3 / n - S2 * S4 / n;
@@ -370,16 +411,14 @@ __global__ void __launch_bounds__(BLOCK) bn_small_dbwd_kernel(const float* __res
   const float k6 = (float)(g * A * rd * rd / n);
   const float vgf = (float)vg, vbf = vbeta ? vbeta[c] : 0.f;
   if (threadIdx.x == 0) adj_gamma[c] = (float)(rd * A);
-  chan_each(B, C, HW, c, [&](int64_t off) {
-    const float xv = x[off], vv = v[off];
-    const float s = bn_y(xv, gr, b) >= 0.f ? 1.f : slope;
-    const float gyh = gz[off] * s;
-    const float xh = (xv - mu) * r;
-    const float pv = vv - k0 - xh * k1;
-    adj_gz[off] = (gr * pv + vgf * xh + vbf) * s;
-    const float q = -gr * (cg * vv + cv * gyh) + vgf * gyh;
-    adj_x[off] = r * (q - qm - xh * qx) - k6 * xh;
-  });
+#pragma unroll
+  for (int i = 0; i < SPER; ++i)
+    if (ix.ok[i]) {
+      const float pv = vv[i] - k0 - xh[i] * k1;
+      adj_gz[ix.off[i]] = (gr * pv + vgf * xh[i] + vbf) * sl[i];
+      const float q = -gr * (cg * vv[i] + cv * gyh[i]) + vgf * gyh[i];
+      adj_x[ix.off[i]] = r * (q - qm - xh[i] * qx) - k6 * xh[i];
+    }
 }
 
 }  // namespace
@@ -415,7 +454,7 @@ int tg_bn_train_fwd(const float* x, float* mean, float* invstd, float* running_m
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   if ((running_mean == nullptr) != (running_var == nullptr)) return TG_EINVAL;
   if (small_case(B, C, HW)) {
-    bn_small_fwd_kernel<<<C, BLOCK, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
+    bn_small_fwd_kernel<<<C, SB, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
                                                             gamma, beta, slope, momentum, eps, z, B, C, HW);
     return tg_launch_status();
   }
@@ -450,7 +489,7 @@ int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const floa
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   hipStream_t st = tg_stream(stream);
   if (small_case(B, C, HW)) {
-    bn_small_bwd_kernel<<<C, BLOCK, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
+    bn_small_bwd_kernel<<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
                                              accumulate);
     return tg_launch_status();
   }
@@ -473,7 +512,7 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, cons
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   hipStream_t st = tg_stream(stream);
   if (small_case(B, C, HW)) {
-    bn_small_dbwd_kernel<<<C, BLOCK, 0, st>>>(v, vgamma, vbeta, gz, x, mean, invstd, gamma, beta, slope, adj_gz, adj_x, adj_gamma,
+    bn_small_dbwd_kernel<<<C, SB, 0, st>>>(v, vgamma, vbeta, gz, x, mean, invstd, gamma, beta, slope, adj_gz, adj_x, adj_gamma,
                                               B, C, HW);
     return tg_launch_status();
   }
