@@ -39,8 +39,9 @@ const char* tg_arch(void);
  * nn.Conv2d(k=3,pad=1) / nn.Conv2d(k=1): models/blocks/generator.py:41,44,52,124
  * models/blocks/discriminator.py:17,63,66,78  models/blocks/attention.py:14-17
  * ks in {1,3}, stride 1, zero pad ks/2.  w is OIHW [Cout][Cin][ks][ks].        */
-int tg_conv2d_fwd(const float* x, const float* w, const float* bias /*nullable*/, float* y,
-                  int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+int tg_conv2d_fwd(const float* x, const float* w, const float* bias /*nullable*/,
+                  const float* residual /*nullable: y = conv + bias + residual (x + h, generator.py:62)*/,
+                  float* y, int B, int Cin, int Cout, int H, int W, int ks, void* stream);
 /* gx = d/dx: correlation of gy with the transposed, spatially flipped filter
  * (what autograd's convolution_backward computes for grad_input)              */
 int tg_conv2d_dgrad(const float* gy, const float* w, float* gx,
@@ -115,7 +116,8 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma /*nullable*/, const float
  * H, W are the dims of the SMALL side for up2x (output 2H x 2W) and of the LARGE
  * (input) side for pool2; both must be even for pool2.                          */
 int tg_up2x(const float* x, float* y, float alpha, int BC, int H, int W, void* stream);
-int tg_pool2(const float* x, float* y, float alpha, int BC, int H, int W, void* stream);
+int tg_pool2(const float* x, const float* residual /*nullable: y = residual + pooled (discriminator.py:95)*/,
+             float* y, float alpha, int BC, int H, int W, void* stream);
 /* F.interpolate(scale_factor=0.5, mode='bilinear', align_corners=True) discriminator.py:55-57
  * input HxW -> output floor(H/2) x floor(W/2); _bwd is its transpose (scatter-free gather form) */
 int tg_bilinear_half_fwd(const float* x, float* y, int BC, int H, int W, void* stream);

@@ -272,8 +272,8 @@ struct WeightStager {
 // =========================================================================== forward / dgrad
 template <class G, int KS, int MF, int MT, bool DGRAD>
 __global__ void __launch_bounds__(CT_THREADS)
-conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-                Shape s, int vec_x, int vec_w) {
+conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                const float* __restrict__ residual /*nullable, same shape as y*/, float* __restrict__ y, Shape s, int vec_x, int vec_w) {
   using P = Patch<G, KS>;
   constexpr bool WK = (G::NPIX == 64);        // waves split K (same pixels) instead of pixels
   constexpr int CT = MF * MT;
@@ -392,7 +392,11 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
         if (WK && (r / (NREG / 4)) != wave) continue;
         const int row = (MF == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * h) : (h * 4 + r);
         const int co = co0 + m * MF + row;
-        if (co < s.Cout) y[base + co * cstride] = acc[m][n][r] + (bias ? bias[co] : 0.f);
+        if (co < s.Cout) {
+          float o = acc[m][n][r] + (bias ? bias[co] : 0.f);
+          if (residual) o += residual[base + co * cstride];
+          y[base + co * cstride] = o;
+        }
       }
     }
   }
@@ -626,7 +630,7 @@ static inline int geo_tiles(GeoId g, int B, int H, int W) {
 static inline int plane_vec_ok(const void* p, int W) { return (W % 4 == 0) && tg_aligned16(p); }
 
 template <class G, int KS, bool DGRAD>
-int launch_fwd_geo(const float* x, const float* w, const float* bias, float* y, Shape s, hipStream_t st) {
+int launch_fwd_geo(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
   const int tiles = num_tiles<G>(s.B, s.H, s.W);
   constexpr bool WK = (G::NPIX == 64);
   const int vx = plane_vec_ok(x, s.W);
@@ -639,38 +643,38 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, float* y, 
     if constexpr (!WK) {
       if (s.Cout > 32) {
         dim3 grid(tiles, (s.Cout + 63) / 64);
-        conv_fwd_kernel<G, KS, 32, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s, vx, vw);
+        conv_fwd_kernel<G, KS, 32, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, vx, vw);
         done = true;
       }
     }
     if (!done) {
       dim3 grid(tiles, (s.Cout + 31) / 32);
-      conv_fwd_kernel<G, KS, 32, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s, vx, vw);
+      conv_fwd_kernel<G, KS, 32, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, vx, vw);
     }
   } else {
     if (s.Cout > 16) {
       dim3 grid(tiles, (s.Cout + 31) / 32);
-      conv_fwd_kernel<G, KS, 16, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s, vx, vw);
+      conv_fwd_kernel<G, KS, 16, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, vx, vw);
     } else {
       dim3 grid(tiles, 1);
-      conv_fwd_kernel<G, KS, 16, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, y, s, vx, vw);
+      conv_fwd_kernel<G, KS, 16, 1, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, vx, vw);
     }
   }
   return tg_launch_status();
 }
 
 template <int KS, bool DGRAD>
-int launch_fwd(const float* x, const float* w, const float* bias, float* y, Shape s, hipStream_t st) {
+int launch_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
   // small layers: if 256-pixel tiles give fewer than ~2 workgroups per CU, use 64-pixel tiles whose
   // waves split K (4x the workgroups, each wave 1/4 of the k-groups)
   const GeoId g = pick_geo(s.H, s.W);
   const int64_t wgs256 = (int64_t)geo_tiles(g, s.B, s.H, s.W) * ((s.Cout + 63) / 64);
   const bool ksplit = (g != GEO_X) && wgs256 < 512 && s.Cin >= 16;
   switch (g) {
-    case GEO_4: return ksplit ? launch_fwd_geo<G4k, KS, DGRAD>(x, w, bias, y, s, st) : launch_fwd_geo<G4, KS, DGRAD>(x, w, bias, y, s, st);
-    case GEO_8: return ksplit ? launch_fwd_geo<G8k, KS, DGRAD>(x, w, bias, y, s, st) : launch_fwd_geo<G8, KS, DGRAD>(x, w, bias, y, s, st);
-    case GEO_16: return ksplit ? launch_fwd_geo<G16k, KS, DGRAD>(x, w, bias, y, s, st) : launch_fwd_geo<G16, KS, DGRAD>(x, w, bias, y, s, st);
-    default: return launch_fwd_geo<GX, KS, DGRAD>(x, w, bias, y, s, st);
+    case GEO_4: return ksplit ? launch_fwd_geo<G4k, KS, DGRAD>(x, w, bias, residual, y, s, st) : launch_fwd_geo<G4, KS, DGRAD>(x, w, bias, residual, y, s, st);
+    case GEO_8: return ksplit ? launch_fwd_geo<G8k, KS, DGRAD>(x, w, bias, residual, y, s, st) : launch_fwd_geo<G8, KS, DGRAD>(x, w, bias, residual, y, s, st);
+    case GEO_16: return ksplit ? launch_fwd_geo<G16k, KS, DGRAD>(x, w, bias, residual, y, s, st) : launch_fwd_geo<G16, KS, DGRAD>(x, w, bias, residual, y, s, st);
+    default: return launch_fwd_geo<GX, KS, DGRAD>(x, w, bias, residual, y, s, st);
   }
 }
 
@@ -723,12 +727,13 @@ static inline int check_shape(int B, int Cin, int Cout, int H, int W, int ks) {
 
 extern "C" {
 
-int tg_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int ks,
-                  void* stream) {
+int tg_conv2d_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, int B, int Cin, int Cout,
+                  int H, int W, int ks, void* stream) {
   TG_CHECK_PTR(x); TG_CHECK_PTR(w); TG_CHECK_PTR(y);
   if (int rc = check_shape(B, Cin, Cout, H, W, ks)) return rc;
   Shape s{B, Cin, Cout, H, W};
-  return ks == 3 ? launch_fwd<3, false>(x, w, bias, y, s, tg_stream(stream)) : launch_fwd<1, false>(x, w, bias, y, s, tg_stream(stream));
+  return ks == 3 ? launch_fwd<3, false>(x, w, bias, residual, y, s, tg_stream(stream))
+                 : launch_fwd<1, false>(x, w, bias, residual, y, s, tg_stream(stream));
 }
 
 int tg_conv2d_dgrad(const float* gy, const float* w, float* gx, int B, int Cin, int Cout, int H, int W, int ks, void* stream) {
@@ -736,7 +741,8 @@ int tg_conv2d_dgrad(const float* gy, const float* w, float* gx, int B, int Cin, 
   if (int rc = check_shape(B, Cin, Cout, H, W, ks)) return rc;
   // a forward convolution whose input channels are the original Cout and output channels the original Cin
   Shape s{B, Cout, Cin, H, W};
-  return ks == 3 ? launch_fwd<3, true>(gy, w, nullptr, gx, s, tg_stream(stream)) : launch_fwd<1, true>(gy, w, nullptr, gx, s, tg_stream(stream));
+  return ks == 3 ? launch_fwd<3, true>(gy, w, nullptr, nullptr, gx, s, tg_stream(stream))
+                 : launch_fwd<1, true>(gy, w, nullptr, nullptr, gx, s, tg_stream(stream));
 }
 
 size_t tg_conv2d_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ks) {

@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(RS_BLOCK) up2x_scalar(const float* __restrict_
 
 // vector path: one thread per output PAIR: float4 from row 2h and row 2h+1
 __global__ void __launch_bounds__(RS_BLOCK) pool2_vec(const float* __restrict__ x, float* __restrict__ y, float alpha,
-                                                      int64_t npairs, int OW2 /* = W/4 */) {
+                                                      int64_t npairs, int OW2 /* = W/4 */, const float* __restrict__ residual) {
   for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < npairs; i += gridDim.x * (int64_t)RS_BLOCK) {
     const int64_t orow = i / OW2;          // bc*OH + oh
     const int op = (int)(i - orow * OW2);
@@ -48,11 +48,16 @@ __global__ void __launch_bounds__(RS_BLOCK) pool2_vec(const float* __restrict__ 
     float2 o;
     o.x = alpha * ((r0.x + r0.y) + (r1.x + r1.y));
     o.y = alpha * ((r0.z + r0.w) + (r1.z + r1.w));
+    if (residual) {
+      const float2 q = *reinterpret_cast<const float2*>(residual + orow * (int64_t)(2 * OW2) + 2 * op);
+      o.x = q.x + o.x;
+      o.y = q.y + o.y;
+    }
     *reinterpret_cast<float2*>(y + orow * (int64_t)(2 * OW2) + 2 * op) = o;
   }
 }
 __global__ void __launch_bounds__(RS_BLOCK) pool2_scalar(const float* __restrict__ x, float* __restrict__ y, float alpha,
-                                                         int64_t nout, int H, int W) {
+                                                         int64_t nout, int H, int W, const float* __restrict__ residual) {
   const int OW = W / 2, OH = H / 2;
   for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < nout; i += gridDim.x * (int64_t)RS_BLOCK) {
     const int ow = (int)(i % OW);
@@ -60,7 +65,8 @@ __global__ void __launch_bounds__(RS_BLOCK) pool2_scalar(const float* __restrict
     const int oh = (int)(t % OH);
     const int64_t bc = t / OH;
     const float* s = x + (bc * H + 2 * oh) * W + 2 * ow;
-    y[i] = alpha * ((s[0] + s[1]) + (s[W] + s[W + 1]));
+    const float o = alpha * ((s[0] + s[1]) + (s[W] + s[W + 1]));
+    y[i] = residual ? residual[i] + o : o;
   }
 }
 
@@ -254,16 +260,16 @@ int tg_up2x(const float* x, float* y, float alpha, int BC, int H, int W, void* s
   return tg_launch_status();
 }
 
-int tg_pool2(const float* x, float* y, float alpha, int BC, int H, int W, void* stream) {
+int tg_pool2(const float* x, const float* residual, float* y, float alpha, int BC, int H, int W, void* stream) {
   TG_CHECK_PTR(x); TG_CHECK_PTR(y); TG_CHECK_POS(BC); TG_CHECK_POS(H); TG_CHECK_POS(W);
   if ((H & 1) || (W & 1)) return TG_EUNSUPPORTED;
   hipStream_t st = tg_stream(stream);
-  if (W % 4 == 0 && tg_aligned16(x) && ((uintptr_t)y & 7) == 0) {
+  if (W % 4 == 0 && tg_aligned16(x) && ((uintptr_t)y & 7) == 0 && ((uintptr_t)residual & 7) == 0) {
     const int64_t npairs = (int64_t)BC * (H / 2) * (W / 4);
-    pool2_vec<<<tg_ew_grid(npairs, RS_BLOCK), RS_BLOCK, 0, st>>>(x, y, alpha, npairs, W / 4);
+    pool2_vec<<<tg_ew_grid(npairs, RS_BLOCK), RS_BLOCK, 0, st>>>(x, y, alpha, npairs, W / 4, residual);
   } else {
     const int64_t nout = (int64_t)BC * (H / 2) * (W / 2);
-    pool2_scalar<<<tg_ew_grid(nout, RS_BLOCK), RS_BLOCK, 0, st>>>(x, y, alpha, nout, H, W);
+    pool2_scalar<<<tg_ew_grid(nout, RS_BLOCK), RS_BLOCK, 0, st>>>(x, y, alpha, nout, H, W, residual);
   }
   return tg_launch_status();
 }

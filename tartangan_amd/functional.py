@@ -47,14 +47,19 @@ def _grad_sink(p):
 
 # =========================================================================== conv
 class _ConvFwd(Function):
+    """y = conv(x, w) + bias [+ residual]; the residual add of the reference's blocks (x + h) rides in the epilogue."""
+
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, residual=None):
         x, w = x.contiguous(), w.contiguous()
         B, Cin, H, W = x.shape
         Cout, ks = w.shape[0], w.shape[2]
         y = x.new_empty(B, Cout, H, W)
-        K().conv2d_fwd(x, w, bias, y, B, Cin, Cout, H, W, ks)
+        if residual is not None:
+            residual = residual.contiguous()
+        K().conv2d_fwd(x, w, bias, residual, y, B, Cin, Cout, H, W, ks)
         ctx.save_for_backward(x, w, bias)
+        ctx.has_residual = residual is not None
         return y
 
     @staticmethod
@@ -74,7 +79,7 @@ class _ConvFwd(Function):
                 gw = _ConvWgrad.apply(x, gy, w.shape[2])
             if need_b:
                 gb = _ChannelSum.apply(gy)
-        return gx, gw, gb
+        return gx, gw, gb, (gy if ctx.has_residual and ctx.needs_input_grad[3] else None)
 
 
 class _ConvDgrad(Function):
@@ -94,7 +99,7 @@ class _ConvDgrad(Function):
         v = v.contiguous()
         a_gy = a_w = None
         if ctx.needs_input_grad[0]:
-            a_gy = _ConvFwd.apply(v, w, None)
+            a_gy = _ConvFwd.apply(v, w, None, None)
         if ctx.needs_input_grad[1]:
             a_w = _ConvWgrad.apply(v, gy, w.shape[2])
         return a_gy, a_w
@@ -124,7 +129,7 @@ class _ConvWgrad(Function):
         if ctx.needs_input_grad[0]:
             a_x = _ConvDgrad.apply(gy, vw)
         if ctx.needs_input_grad[1]:
-            a_gy = _ConvFwd.apply(x, vw, None)
+            a_gy = _ConvFwd.apply(x, vw, None, None)
         return a_x, a_gy, None
 
 
@@ -160,9 +165,9 @@ class _ChannelBcast(Function):
         return _ChannelSum.apply(g), None
 
 
-def conv2d(x, weight, bias=None):
-    """3x3 (pad 1) or 1x1 (pad 0) stride-1 convolution, NCHW fp32."""
-    return _ConvFwd.apply(x, weight, bias)
+def conv2d(x, weight, bias=None, residual=None):
+    """3x3 (pad 1) or 1x1 (pad 0) stride-1 convolution, NCHW fp32; optional fused ``+ residual``."""
+    return _ConvFwd.apply(x, weight, bias, residual)
 
 
 # =========================================================================== GEMM
@@ -336,28 +341,34 @@ class _Up2x(Function):
 
 
 class _Pool2(Function):
+    """alpha * (2x2 sum pool) [+ residual]"""
+
     @staticmethod
-    def forward(ctx, x, alpha):
+    def forward(ctx, x, alpha, residual=None):
         x = x.contiguous()
         B, C, H, W = x.shape
         if H % 2 or W % 2:
             raise RuntimeError('pool2 needs even spatial dims')
         y = x.new_empty(B, C, H // 2, W // 2)
-        K().pool2(x, y, alpha, B * C, H, W)
+        if residual is not None:
+            residual = residual.contiguous()
+        K().pool2(x, residual, y, alpha, B * C, H, W)
         ctx.alpha = alpha
+        ctx.has_residual = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, g):
-        return _Up2x.apply(g, ctx.alpha), None
+        return _Up2x.apply(g, ctx.alpha), None, (g if ctx.has_residual and ctx.needs_input_grad[2] else None)
 
 
 def upsample_nearest2x(x):
     return _Up2x.apply(x, 1.0)
 
 
-def avg_pool2(x):
-    return _Pool2.apply(x, 0.25)
+def avg_pool2(x, residual=None):
+    """nn.AvgPool2d(2) [+ residual]"""
+    return _Pool2.apply(x, 0.25, residual)
 
 
 class _BilinearHalf(Function):

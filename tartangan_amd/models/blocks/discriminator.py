@@ -51,11 +51,10 @@ class ResidualDiscriminatorBlock(nn.Module):
         self.interpolate = interpolate
 
     def forward(self, x):
-        h = run_layers(self.convs, x)
-        x = self.interpolate(x)
+        shortcut = self.interpolate(x)
         if self.project_input is not None:
-            x = run_layers(self.project_input, x)
-        return TF.add(x, h)
+            shortcut = run_layers(self.project_input, shortcut)
+        return run_layers(self.convs, x, residual=shortcut)          # x + h, the add fused into the avg-pool
 
 
 class DiscriminatorOutput(nn.Module):

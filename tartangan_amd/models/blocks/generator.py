@@ -38,10 +38,8 @@ class ResidualGeneratorBlock(nn.Module):
     def forward(self, x):
         if self.upsample:
             x = TF.upsample_nearest2x(x)
-        h = run_layers(self.convs, x)
-        if self.project_input is not None:
-            x = run_layers(self.project_input, x)
-        return TF.add(x, h)
+        shortcut = x if self.project_input is None else run_layers(self.project_input, x)
+        return run_layers(self.convs, x, residual=shortcut)          # x + h, the add fused into the last conv
 
 
 class GeneratorInputMLP(nn.Module):

@@ -75,19 +75,28 @@ class BatchNorm2d(nn.BatchNorm2d):
         return self._run(x, slope)
 
 
-def run_layers(seq, x):
+def run_layers(seq, x, residual=None):
     """Apply an ``nn.Sequential`` the way ``Sequential.forward`` would, fusing each
-    (BatchNorm2d, LeakyReLU) pair into one kernel pass."""
+    (BatchNorm2d, LeakyReLU) pair into one kernel pass.  ``residual`` (the block's shortcut) is added to the
+    result; when the last layer is a Conv2d or an AvgPool2d the add rides in that kernel's epilogue."""
     mods = list(seq)
     i = 0
     while i < len(mods):
         m = mods[i]
+        last = i == len(mods) - 1
         if (isinstance(m, BatchNorm2d) and i + 1 < len(mods) and isinstance(mods[i + 1], LeakyReLU)):
             x = m.forward_act(x, mods[i + 1].negative_slope)
             i += 2
+            continue
+        if last and residual is not None and type(m) is Conv2d:
+            x, residual = TF.conv2d(x, m.weight, m.bias, residual), None
+        elif last and residual is not None and type(m) is AvgPool2d:
+            x, residual = TF.avg_pool2(x, residual), None
         else:
             x = m(x)
-            i += 1
+        i += 1
+    if residual is not None:
+        x = TF.add(residual, x)
     return x
 
 

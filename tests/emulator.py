@@ -23,8 +23,9 @@ class Emulator:
     name = 'emulator'
 
     # ---------------------------------------------------------------- conv
-    def conv2d_fwd(self, x, w, bias, y, B, Cin, Cout, H, W, ks):
-        y.copy_(F.conv2d(_v(x, B, Cin, H, W), _v(w, Cout, Cin, ks, ks), bias, padding=ks // 2))
+    def conv2d_fwd(self, x, w, bias, residual, y, B, Cin, Cout, H, W, ks):
+        r = F.conv2d(_v(x, B, Cin, H, W), _v(w, Cout, Cin, ks, ks), bias, padding=ks // 2)
+        y.copy_(r if residual is None else _v(residual, B, Cout, H, W) + r)
         return 0
 
     def conv2d_dgrad(self, gy, w, gx, B, Cin, Cout, H, W, ks):
@@ -155,8 +156,9 @@ class Emulator:
         _v(y, BC, 2 * H, 2 * W).copy_(alpha * _v(x, BC, H, W).repeat_interleave(2, 1).repeat_interleave(2, 2))
         return 0
 
-    def pool2(self, x, y, alpha, BC, H, W):
-        _v(y, BC, H // 2, W // 2).copy_(alpha * 4 * F.avg_pool2d(_v(x, 1, BC, H, W), 2)[0])
+    def pool2(self, x, residual, y, alpha, BC, H, W):
+        r = alpha * 4 * F.avg_pool2d(_v(x, 1, BC, H, W), 2)[0]
+        _v(y, BC, H // 2, W // 2).copy_(r if residual is None else _v(residual, BC, H // 2, W // 2) + r)
         return 0
 
     def bilinear_half_fwd(self, x, y, BC, H, W):

@@ -49,5 +49,5 @@ def test_bad_arguments_return_codes(lib):
     lib.tg_add.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
     assert lib.tg_add(None, None, None, 16, None) == -1          # TG_EINVAL, nothing launched
     lib.tg_conv2d_fwd.restype = ctypes.c_int
-    lib.tg_conv2d_fwd.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
-    assert lib.tg_conv2d_fwd(None, None, None, None, 1, 1, 1, 4, 4, 3, None) == -1
+    lib.tg_conv2d_fwd.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+    assert lib.tg_conv2d_fwd(None, None, None, None, None, 1, 1, 1, 4, 4, 3, None) == -1

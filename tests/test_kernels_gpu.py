@@ -62,8 +62,9 @@ CONV_SHAPES = [
 def test_conv_fwd(K, shape):
     B, Cin, Cout, H, W, ks = shape
     x, w, b = rnd(B, Cin, H, W), rnd(Cout, Cin, ks, ks, scale=0.2), rnd(Cout)
-    run_both(K, 'conv2d_fwd', [x, w, b, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, ks], [3], tol=2e-5)
-    run_both(K, 'conv2d_fwd', [x, w, None, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, ks], [3], tol=2e-5)
+    run_both(K, 'conv2d_fwd', [x, w, b, None, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, ks], [4], tol=2e-5)
+    run_both(K, 'conv2d_fwd', [x, w, None, None, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, ks], [4], tol=2e-5)
+    run_both(K, 'conv2d_fwd', [x, w, b, rnd(B, Cout, H, W, seed=7), torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, ks], [4], tol=2e-5)
 
 
 def test_conv_fwd_exact_integer_layout(K):
@@ -71,7 +72,7 @@ def test_conv_fwd_exact_integer_layout(K):
     B, Cin, Cout, H, W = 2, 8, 32, 32, 32
     x = (torch.arange(B * Cin * H * W) % 7 - 3).float().view(B, Cin, H, W)
     w = (torch.arange(Cout * Cin * 9) % 5 - 2).float().view(Cout, Cin, 3, 3)
-    run_both(K, 'conv2d_fwd', [x, w, None, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, 3], [3], atol=0.0)
+    run_both(K, 'conv2d_fwd', [x, w, None, None, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, 3], [4], atol=0.0)
     run_both(K, 'conv2d_dgrad', [torch.round(rnd(B, Cout, H, W) * 2), w, torch.zeros(B, Cin, H, W), B, Cin, Cout, H, W, 3],
              [2], atol=0.0)
 
@@ -114,7 +115,7 @@ def test_conv_wgrad_is_deterministic(K):
 def test_conv_rejects_unsupported(K):
     x = torch.zeros(1, 4, 8, 8).cuda()
     with pytest.raises(RuntimeError):
-        K.conv2d_fwd(x, torch.zeros(4, 4, 5, 5).cuda(), None, torch.zeros(1, 4, 8, 8).cuda(), 1, 4, 4, 8, 8, 5)
+        K.conv2d_fwd(x, torch.zeros(4, 4, 5, 5).cuda(), None, None, torch.zeros(1, 4, 8, 8).cuda(), 1, 4, 4, 8, 8, 5)
 
 
 BN_SHAPES = [(4, 16, 64 * 64), (8, 128, 16), (3, 3, 32 * 32), (2, 32, 128 * 128), (5, 100, 8 * 8), (64, 128, 1), (2, 7, 12 * 10),
@@ -155,7 +156,8 @@ def test_resample(K, shape):
     x = rnd(BC, H, W)
     for alpha in (1.0, 0.25):
         run_both(K, 'up2x', [x, torch.zeros(BC, 2 * H, 2 * W), alpha, BC, H, W], [1], tol=1e-6)
-        run_both(K, 'pool2', [x, torch.zeros(BC, H // 2, W // 2), alpha, BC, H, W], [1], tol=1e-6)
+        run_both(K, 'pool2', [x, None, torch.zeros(BC, H // 2, W // 2), alpha, BC, H, W], [2], tol=1e-6)
+        run_both(K, 'pool2', [x, rnd(BC, H // 2, W // 2, seed=3), torch.zeros(BC, H // 2, W // 2), alpha, BC, H, W], [2], tol=1e-6)
     run_both(K, 'bilinear_half_fwd', [x, torch.zeros(BC, H // 2, W // 2), BC, H, W], [1], tol=1e-5)   # lambda = r - floor(r) carries ulp(r)
     run_both(K, 'bilinear_half_bwd', [rnd(BC, H // 2, W // 2), torch.zeros(BC, H, W), BC, H, W], [1], tol=1e-5)
     idx = torch.zeros(BC, H // 2, W // 2, dtype=torch.uint8)

@@ -27,7 +27,7 @@ for Cin, Cout, H, ks in SHAPES:
     y = torch.empty(B, Cout, H, H, device='cuda'); gx = torch.empty_like(x); gw = torch.empty_like(w); gb = torch.empty_like(bias)
     ws = torch.empty(K.conv2d_wgrad_workspace(B, Cin, Cout, H, H, ks) // 4 + 4, device='cuda')
     fl = 2.0 * B * Cin * Cout * H * H * ks * ks
-    t1 = timeit(lambda: K.conv2d_fwd(x, w, bias, y, B, Cin, Cout, H, H, ks))
+    t1 = timeit(lambda: K.conv2d_fwd(x, w, bias, None, y, B, Cin, Cout, H, H, ks))
     t2 = timeit(lambda: K.conv2d_dgrad(gy, w, gx, B, Cin, Cout, H, H, ks))
     t3 = timeit(lambda: K.conv2d_wgrad(x, gy, gw, gb, ws, ws.numel() * 4, B, Cin, Cout, H, H, ks, 0))
     tf = lambda t: fl / (t * 1e-3) / 1e12
