@@ -98,11 +98,25 @@ class KernelTimer:
         for name, fn in self._saved.items():
             setattr(self.K, name, fn)
 
+    @staticmethod
+    def _empty_pair_ms(n=64):
+        """Elapsed time between two events recorded back to back with nothing in between: the fixed cost that an
+        event pair adds around a kernel; subtracted from every record (tiny kernels are otherwise over-counted)."""
+        pairs = []
+        for _ in range(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); b.record()
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        vals = sorted(a.elapsed_time(b) for a, b in pairs)
+        return vals[len(vals) // 2]
+
     def summary(self):
         torch.cuda.synchronize()
+        base = self._empty_pair_ms()
         agg = {}
         for name, args, a, b in self.records:
-            ms = a.elapsed_time(b)
+            ms = max(a.elapsed_time(b) - base, 0.0)
             flops = 0.0
             if name in ('conv2d_fwd', 'conv2d_dgrad'):
                 B, Cin, Cout, H, W, ks = args[-6:]

@@ -89,7 +89,9 @@ class CNNTrainer(Trainer):
         if self.args.grad_penalty:
             d_grad_penalty = TF.scale(gradient_penalty(p_real, real), self.args.grad_penalty)
             d_loss = TF.add(d_loss, d_grad_penalty)
-        d_loss.backward()
+        # same parameter gradients as d_loss.backward(); naming the leaves just spares autograd the gradient
+        # w.r.t. the real images, which the reference computes (real.requires_grad_) and never reads
+        torch.autograd.backward(d_loss, inputs=[p for p in self.d.parameters() if p.requires_grad])
         return d_loss.detach(), (d_grad_penalty.detach() if d_grad_penalty is not None else None)
 
     def _g_phase(self, bs):
