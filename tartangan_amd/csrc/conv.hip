@@ -641,7 +641,8 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, const floa
   if (use32) {
     bool done = false;
     if constexpr (!WK) {
-      if (s.Cout > 32) {
+      // 64-channel tiles halve the patch re-reads but also the workgroup count: only when the grid stays full
+      if (s.Cout > 32 && (int64_t)tiles * ((s.Cout + 63) / 64) >= 768) {
         dim3 grid(tiles, (s.Cout + 63) / 64);
         conv_fwd_kernel<G, KS, 32, 2, DGRAD><<<grid, CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, vx, vw);
         done = true;
@@ -684,7 +685,7 @@ struct WgPlan {
 static inline WgPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int ks) {
   WgPlan p;
   p.tiles = geo_tiles(pick_geo(H, W), B, H, W);
-  p.mtw = Cout > 16 ? 2 : 1;
+  p.mtw = (Cout > 16 && H * W == 64) ? 2 : 1;   // 16-channel tiles keep LDS at 42 KB (3 workgroups/CU): faster except on the tiny 8x8 / 4x4 layers
   p.co_tiles = (Cout + 16 * p.mtw - 1) / (16 * p.mtw);
   const int ckw = (ks == 3) ? WgCfg<3>::CKW : WgCfg<1>::CKW;
   p.ci_chunks = (Cin + ckw - 1) / ckw;
