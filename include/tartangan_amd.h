@@ -197,6 +197,16 @@ int tg_bce_logits(const float* logits, const float* targets, float* loss, float*
 /* *out = alpha * sum x^2  (R1: grad.pow(2).view(B,-1).sum(1).mean(), losses.py:27-29)   */
 int tg_sumsq(const float* x, float alpha, float* out, float* workspace, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------- spectral norm (north_star a15)
+ * The reference never applies spectral norm (prep4web.py:24,33-51 only strips torch.nn.utils.spectral_norm
+ * from a checkpoint); the hook is every block's conv_factory (discriminator.py:28,52, generator.py:34,117).
+ * Semantics pinned against torch.nn.utils.spectral_norm:  n_iter x { v = normalize(W^T u, eps);
+ * u = normalize(W v, eps) } in place, then *sigma = u^T W v (sigma nullable).  W: rows x cols row-major.    */
+int tg_sn_power_iter(const float* W, float* u, float* v, float* sigma /*nullable*/,
+                     int rows, int cols, int n_iter, float eps, void* stream);
+/* out = 1 / x */
+int tg_recip(const float* x, float* out, int64_t n, void* stream);
+
 /* ---------------------------------------------------------------- optimiser / EMA
  * torch.optim.Adam (trainers/cnn.py:84-85), single flat tensor.
  * hyper (device, 6 floats): [lr/bias_correction1, sqrt(bias_correction2), beta1, beta2,

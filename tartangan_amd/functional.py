@@ -674,6 +674,36 @@ def scale_add(s, a, b):
     return _ScaleAddDev.apply(s, a, b)
 
 
+class _Recip(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        K().recip(x, out, x.numel())
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, = ctx.saved_tensors
+        return _Scale.apply(_Mul.apply(_Mul.apply(out, out), g), -1.0)        # d(1/x) = -(1/x)^2
+
+
+def spectral_normalize(weight, u, v, training, n_power_iterations=1, eps=1e-12):
+    """torch.nn.utils.spectral_norm's compute_weight: one power iteration on the (u, v) buffers in place while
+    training, then weight / (u^T W v) with u, v treated as constants -- differentiable twice w.r.t. weight."""
+    rows = weight.shape[0]
+    wmat = weight.reshape(rows, -1)
+    cols = wmat.shape[1]
+    if training and n_power_iterations > 0:
+        with torch.no_grad():
+            K().sn_power_iter(wmat.detach().contiguous(), u, v, None, rows, cols, n_power_iterations, float(eps))
+        u, v = u.clone(), v.clone()      # a later forward updates the buffers in place; this graph keeps its own copy
+    wv = matmul(wmat, v.view(cols, 1)).view(rows)
+    sigma = _Dot.apply(u, wv, 1.0)
+    return _ScaleDev.apply(_Recip.apply(sigma), weight, 1.0)
+
+
 class _LReluBwd(Function):
     """g * lrelu'(x); LeakyReLU forward is the case g is x."""
 

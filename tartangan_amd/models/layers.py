@@ -32,6 +32,29 @@ class Conv2d(nn.Conv2d):
         return TF.conv2d(x, self.weight, self.bias)
 
 
+class SpectralNormConv2d(Conv2d):
+    """``conv_factory`` with spectral normalisation (what ``torch.nn.utils.spectral_norm(nn.Conv2d(...))`` gives):
+    parameters ``weight_orig`` / ``bias``, buffers ``weight_u`` / ``weight_v``, one power iteration per training
+    forward, ``weight = weight_orig / sigma``.  Off by default: the reference's trainers never apply it."""
+
+    def __init__(self, *args, n_power_iterations=1, eps=1e-12, **kw):
+        super().__init__(*args, **kw)
+        weight = self._parameters.pop('weight')
+        self.register_parameter('weight_orig', weight)
+        with torch.no_grad():
+            h, w = weight.shape[0], weight[0].numel()
+            u = nn.functional.normalize(weight.new_empty(h).normal_(0, 1), dim=0, eps=eps)
+            v = nn.functional.normalize(weight.new_empty(w).normal_(0, 1), dim=0, eps=eps)
+        self.register_buffer('weight_u', u)
+        self.register_buffer('weight_v', v)
+        self.n_power_iterations, self.sn_eps = n_power_iterations, eps
+
+    def forward(self, x):
+        w = TF.spectral_normalize(self.weight_orig, self.weight_u, self.weight_v, self.training,
+                                  self.n_power_iterations, self.sn_eps)
+        return TF.conv2d(x, w, self.bias)
+
+
 class Linear(nn.Linear):
     def forward(self, x):
         return TF.linear(x, self.weight, self.bias)

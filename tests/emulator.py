@@ -321,6 +321,20 @@ class Emulator:
         out.copy_(alpha * x.pow(2).sum())
         return 0
 
+    # ---------------------------------------------------------------- spectral norm
+    def sn_power_iter(self, W, u, v, sigma, rows, cols, n_iter, eps):
+        Wm = W.view(rows, cols)
+        for _ in range(n_iter):
+            F.normalize(torch.mv(Wm.t(), u), dim=0, eps=eps, out=v)
+            F.normalize(torch.mv(Wm, v), dim=0, eps=eps, out=u)
+        if sigma is not None:
+            sigma.copy_(torch.dot(u, torch.mv(Wm, v)))
+        return 0
+
+    def recip(self, x, out, n):
+        out.copy_(1.0 / x)
+        return 0
+
     # ---------------------------------------------------------------- optimiser
     def adam_step(self, p, g, m, v, hyper, eps, n):
         step_size, bc2_sqrt, b1, b2, omb1, omb2 = [float(h) for h in hyper]
