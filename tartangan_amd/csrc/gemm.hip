@@ -76,6 +76,52 @@ __global__ void __launch_bounds__(GT) gemm_kernel(const float* __restrict__ A, c
   }
 }
 
+// Skinny product C (M x N) = A (M x K) B (K x N), M <= 16, both row-major, K long: the attention backward's
+// dphi = theta ds / dg = go beta under double backward (M = 4 / 16, K = 1024, N = 256 at 128:3).  The 64x64 tile
+// kernel above would use 4/64 of its rows; here a workgroup owns 64 columns, its 4 waves split K, every B element
+// is read once (coalesced along N) and A is broadcast from LDS.
+constexpr int SK_KC = 256;      // K chunk staged per iteration
+template <int MM>
+__global__ void __launch_bounds__(GT) gemm_skinny_nn_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
+                                                            const float* __restrict__ bias, int M, int N, int K, int lda, int ldb, int ldc,
+                                                            int64_t sA, int64_t sB, int64_t sC, float beta) {
+  __shared__ float As[MM][SK_KC + 1];
+  __shared__ float red[4][MM][64];
+  const int batch = blockIdx.y;
+  A += batch * sA; Bm += batch * sB; C += batch * sC;
+  const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + col;
+  float acc[MM];
+#pragma unroll
+  for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += SK_KC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < MM * SK_KC; e += GT) {
+      const int m = e / SK_KC, k = e - m * SK_KC;
+      As[m][k] = (m < M && k0 + k < K) ? A[(int64_t)m * lda + k0 + k] : 0.f;
+    }
+    __syncthreads();
+    const int kend = min(SK_KC, K - k0);
+    for (int k = ks; k < kend; k += 4) {
+      const float b = (n < N) ? Bm[(int64_t)(k0 + k) * ldb + n] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MM; ++m) acc[m] = fmaf(As[m][k], b, acc[m]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MM; ++m) red[ks][m][col] = acc[m];
+  __syncthreads();
+  for (int e = threadIdx.x; e < MM * 64; e += GT) {
+    const int m = e >> 6, c = e & 63;
+    const int gn = blockIdx.x * 64 + c;
+    if (m < M && gn < N) {
+      float r = (red[0][m][c] + red[1][m][c]) + (red[2][m][c] + red[3][m][c]) + (bias ? bias[gn] : 0.f);
+      if (beta != 0.f) r += beta * C[(int64_t)m * ldc + gn];
+      C[(int64_t)m * ldc + gn] = r;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tg_gemm(const float* A, const float* Bm, float* C, const float* bias_n, int M, int N, int K, int lda, int ldb,
@@ -85,8 +131,14 @@ extern "C" int tg_gemm(const float* A, const float* Bm, float* C, const float* b
   TG_CHECK_POS(M); TG_CHECK_POS(N); TG_CHECK_POS(K); TG_CHECK_POS(batch);
   if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return TG_EINVAL;
   if (batch > 65535) return TG_EUNSUPPORTED;
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
   hipStream_t st = tg_stream(stream);
+  if (!transA && !transB && M <= 16 && K >= 256) {
+    dim3 sgrid((N + 63) / 64, batch);
+    if (M <= 4) gemm_skinny_nn_kernel<4><<<sgrid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
+    else gemm_skinny_nn_kernel<16><<<sgrid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
+    return tg_launch_status();
+  }
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
   if (transA && transB) gemm_kernel<true, true><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
   else if (transA) gemm_kernel<true, false><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
   else if (transB) gemm_kernel<false, true><<<grid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);

@@ -177,6 +177,7 @@ GEMM_CASES = [
     # M, N, K, ta, tb, batch
     (64, 2048, 256, 0, 1, 1), (64, 1, 128, 0, 1, 1), (512, 128, 20, 0, 1, 1), (256, 64, 16, 1, 0, 3),
     (16, 256, 64, 0, 1, 3), (4096, 1024, 4, 1, 0, 2), (100, 37, 19, 1, 1, 2), (33, 65, 17, 0, 0, 1),
+    (4, 256, 1024, 0, 0, 3), (16, 256, 1024, 0, 0, 2), (3, 70, 300, 0, 0, 2), (9, 130, 513, 0, 0, 1),
 ]
 
 
