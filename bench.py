@@ -118,17 +118,18 @@ class KernelTimer:
         for name, args, a, b in self.records:
             ms = max(a.elapsed_time(b) - base, 0.0)
             flops = 0.0
-            if name in ('conv2d_fwd', 'conv2d_dgrad'):
-                B, Cin, Cout, H, W, ks = args[-6:]
-                flops = 2.0 * B * Cin * Cout * H * W * ks * ks
-            elif name == 'conv2d_wgrad':
-                B, Cin, Cout, H, W, ks = args[-6:]
+            if name in CONV_DIMS:
+                B, Cin, Cout, H, W, ks = args[CONV_DIMS[name]]
                 flops = 2.0 * B * Cin * Cout * H * W * ks * ks
             d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0))
             d['ms'] += ms
             d['launches'] += 1
             d['flops'] += flops
         return agg
+
+
+# where (B, Cin, Cout, H, W, ks) sit in each conv entry point's argument list (include/tartangan_amd.h)
+CONV_DIMS = {'conv2d_fwd': slice(5, 11), 'conv2d_dgrad': slice(3, 9), 'conv2d_wgrad': slice(6, 12)}
 
 
 def cpu_baseline(config, kind, batch):

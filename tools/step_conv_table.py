@@ -15,7 +15,7 @@ torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0.0, 0, 0.0])
 for name, args, a, b in kt.records:
     if not name.startswith('conv2d'): continue
-    Bb, Cin, Cout, H, W, ks = args[-7:-1] if name == 'conv2d_wgrad' else args[-6:]
+    Bb, Cin, Cout, H, W, ks = args[bench.CONV_DIMS[name]]
     key = (name, Cin, Cout, H, ks)
     ms = a.elapsed_time(b)
     agg[key][0] += ms; agg[key][1] += 1; agg[key][2] += 2.0 * Bb * Cin * Cout * H * W * ks * ks
