@@ -106,8 +106,11 @@ struct PatchStager {
   float4 v[NV];
   float hv[NH > 0 ? NH : 1];
 
-  struct RowRef { int ci, lrow; bool ok; int64_t goff; };
-  // row index -> (channel, LDS row, validity, global offset of image column 0 of that row)
+  // Addressing: ONE wave-uniform 64-bit base per (tile, chunk) -- the element at (b0, c0, h0 - PAD, w0 - PAD), computed
+  // on the scalar unit -- plus a per-lane 32-bit BYTE offset built from 24-bit multiplies (full rate; the host checks
+  // the extents, see check_shape).  64-bit per-lane products (v_mad_u64_u32 / v_mul_lo_u32 are quarter rate) used to
+  // cost the 16/32-channel layers as many issue cycles as their MFMAs.
+  struct RowRef { bool ok; uint32_t boff; };
   __device__ __forceinline__ static RowRef row_ref(int row, const Shape& s, int C, int c0, const TileCoord& tc) {
     const int r = row % P::PH;
     const int t = row / P::PH;
@@ -115,15 +118,19 @@ struct PatchStager {
     const int ci = t / G::NI;
     const int b = tc.b0 + img, cc = c0 + ci, hh = tc.h0 + r - P::PAD;
     RowRef o;
-    o.ci = ci;
-    o.lrow = img * P::PH + r;
     o.ok = (b < s.B) && (cc < C) && (hh >= 0) && (hh < s.H);
-    o.goff = (((int64_t)b * C + cc) * s.H + hh) * s.W;
+    o.boff = (__umul24(__umul24(img, C) + ci, s.H * s.W) + __umul24(r, s.W)) << 2;
     return o;
   }
+  __device__ __forceinline__ static const char* tile_base(const float* __restrict__ x, const Shape& s, int C, int c0, const TileCoord& tc) {
+    return reinterpret_cast<const char*>(x) + ((((int64_t)tc.b0 * C + c0) * s.H + (tc.h0 - P::PAD)) * s.W + (tc.w0 - P::PAD)) * 4;
+  }
+  template <class T>
+  __device__ __forceinline__ static T ld(const char* base, uint32_t boff) { return *reinterpret_cast<const T*>(base + boff); }
 
   __device__ __forceinline__ void load(const float* __restrict__ x, const Shape& s, int C, int c0, const TileCoord& tc, bool vec) {
-    if (vec) {
+    const char* base = tile_base(x, s, C, c0, tc);
+    if (vec) {                                            // W % 4 == 0: a quad is all-in or all-out
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int e = threadIdx.x + i * CT_THREADS;
@@ -131,8 +138,7 @@ struct PatchStager {
         if (e < ROWS * Q) {
           const int q = e % Q;
           const RowRef rr = row_ref(e / Q, s, C, c0, tc);
-          const int ww = tc.w0 + 4 * q;
-          if (rr.ok && ww < s.W) val = *reinterpret_cast<const float4*>(x + rr.goff + ww);   // W % 4 == 0: all-in or all-out
+          if (rr.ok && tc.w0 + 4 * q < s.W) val = ld<float4>(base, rr.boff + 4 * (P::PAD + 4 * q));
         }
         v[i] = val;
       }
@@ -145,12 +151,12 @@ struct PatchStager {
           const int q = e % Q;
           const RowRef rr = row_ref(e / Q, s, C, c0, tc);
           const int ww = tc.w0 + 4 * q;
+          const uint32_t off = rr.boff + 4 * (P::PAD + 4 * q);
           if (rr.ok) {
-            const float* src = x + rr.goff + ww;
-            if (ww < s.W) val.x = src[0];
-            if (ww + 1 < s.W) val.y = src[1];
-            if (ww + 2 < s.W) val.z = src[2];
-            if (ww + 3 < s.W) val.w = src[3];
+            if (ww < s.W) val.x = ld<float>(base, off);
+            if (ww + 1 < s.W) val.y = ld<float>(base, off + 4);
+            if (ww + 2 < s.W) val.z = ld<float>(base, off + 8);
+            if (ww + 3 < s.W) val.w = ld<float>(base, off + 12);
           }
         }
         v[i] = val;
@@ -164,7 +170,7 @@ struct PatchStager {
         if (e < NHALO) {
           const RowRef rr = row_ref(e >> 1, s, C, c0, tc);
           const int ww = (e & 1) ? tc.w0 + G::TW : tc.w0 - 1;
-          if (rr.ok && ww >= 0 && ww < s.W) val = x[rr.goff + ww];
+          if (rr.ok && ww >= 0 && ww < s.W) val = ld<float>(base, rr.boff + ((e & 1) ? 4 * (G::TW + 1) : 0));
         }
         hv[i] = val;
       }
@@ -231,8 +237,9 @@ struct WeightStager {
         const int q = e % Q, row = e / Q;
         const bool row_ok = DGRAD ? (ci0 + row < Cin) : (co0 + row < Cout);
         if (row_ok) {
-          const int64_t base = DGRAD ? ((int64_t)(ci0 + row) * Cout + co0) * KK : ((int64_t)(co0 + row) * Cin + ci0) * KK;
-          const float* src = w + base + 4 * q;
+          // wave-uniform base (first row of the slice) + 32-bit lane offset
+          const float* base = w + (DGRAD ? ((int64_t)ci0 * Cout + co0) * KK : ((int64_t)co0 * Cin + ci0) * KK);
+          const float* src = base + (__umul24(row, (DGRAD ? Cout : Cin) * KK) + 4 * q);
           if (vec && 4 * q + 3 < nvalid) {
             val = *reinterpret_cast<const float4*>(src);
           } else {
@@ -270,65 +277,34 @@ struct WeightStager {
 };
 
 // =========================================================================== forward / dgrad
-template <class G, int KS, int MF, int MT, bool DGRAD>
-__global__ void __launch_bounds__(CT_THREADS)
-conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                const float* __restrict__ residual /*nullable, same shape as y*/, float* __restrict__ y, Shape s, int vec_x, int vec_w) {
+template <class G, int KS, int MF, int MT, bool WK>
+struct FwdCore {
   using P = Patch<G, KS>;
-  constexpr bool WK = (G::NPIX == 64);        // waves split K (same pixels) instead of pixels
-  constexpr int CT = MF * MT;
+  static constexpr int CT = MF * MT;
   using WT = WTile<KS, CT, WK>;
-  constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS;
-  constexpr int NT = 64 / MF;                 // pixel sub-tiles per wave (64 pixels per wave)
-  constexpr int KG = (MF == 32) ? 2 : 4;      // k values consumed per MFMA
-  constexpr int NREG = (MF == 32) ? 16 : 4;
-  constexpr int NG = CK / KG;                 // k-groups per chunk
-  constexpr int GSTEP = WK ? 4 : 1;           // WK: wave w takes k-groups w, w+4, ...
+  static constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS;
+  static constexpr int NT = 64 / MF;                 // pixel sub-tiles per wave (64 pixels per wave)
+  static constexpr int KG = (MF == 32) ? 2 : 4;      // k values consumed per MFMA
+  static constexpr int NREG = (MF == 32) ? 16 : 4;
+  static constexpr int NG = CK / KG;                 // k-groups per chunk
+  static constexpr int GSTEP = WK ? 4 : 1;           // WK: wave w takes k-groups w, w+4, ...
   static_assert(!WK || NG % 4 == 0, "K-split needs a multiple of 4 k-groups per chunk");
-  constexpr int STAGE = CK * P::CIS + WT::SIZE;
-  constexpr int REDF = WK ? 4 * MT * NT * NREG * 64 : 0;
-  __shared__ __attribute__((aligned(16))) float lds[STAGE > REDF ? STAGE : REDF];
-  float* pl = lds;
-  float* wl = lds + CK * P::CIS;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane % MF, h = lane / MF;     // MF=32: h in {0,1}; MF=16: h in {0..3}
-  const TileCoord tc = decode_tile<G>(blockIdx.x, s.H, s.W);
-  const int co0 = blockIdx.y * CT;
-  const int pix0 = WK ? 0 : wave * 64;
-  const int g0 = WK ? wave : 0;
-
-  int lane_b[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) lane_b[n] = (h + g0 * KG) * P::CIS + pix_off<G, KS>(pix0 + n * MF + j);
-  const int lane_a = ((h + g0 * KG) * KK) * CTS + j;
-
   using acc_t = typename std::conditional<MF == 32, f32x16, f32x4>::type;
-  acc_t acc[MT][NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int r = 0; r < NREG; ++r) acc[m][n][r] = 0.f;
 
-  PatchStager<G, KS, CK> ps;
-  WeightStager<KS, CT, DGRAD, WK> ws;
-  ps.load(x, s, s.Cin, 0, tc, vec_x);
-  ws.load(w, s.Cin, s.Cout, 0, co0, vec_w);
+  __device__ __forceinline__ static void zero(acc_t (&acc)[MT][NT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) acc[m][n][r] = 0.f;
+  }
 
-  for (int ci0 = 0; ci0 < s.Cin; ci0 += CK) {
-    __syncthreads();                          // every wave is done reading the previous chunk
-    ps.store(pl);
-    ws.store(wl);
-    __syncthreads();
-    if (ci0 + CK < s.Cin) {                   // next chunk's global loads fly under this chunk's MFMAs
-      ps.load(x, s, s.Cin, ci0 + CK, tc, vec_x);
-      ws.load(w, s.Cin, s.Cout, ci0 + CK, co0, vec_w);
-    }
-    // No per-k-group branch here: channels past Cin are zero in LDS (a ragged last chunk just multiplies
-    // zeros).  A wave-uniform `if` around the MFMA block made hipcc shuttle all accumulators between
-    // VGPRs and AGPRs on both sides of it (64 v_accvgpr moves + s_nop 15 per 18 MFMAs).
+  // One staged Cin chunk.  No per-k-group branch here: channels past Cin are zero in LDS (a ragged last chunk just
+  // multiplies zeros).  A wave-uniform `if` around the MFMA block made hipcc shuttle all accumulators between
+  // VGPRs and AGPRs on both sides of it (64 v_accvgpr moves + s_nop 15 per 18 MFMAs).
+  __device__ __forceinline__ static void mfma_chunk(acc_t (&acc)[MT][NT], const float* __restrict__ pl, const float* __restrict__ wl,
+                                                    int lane_a, const int (&lane_b)[NT]) {
 #pragma unroll
     for (int gi = 0; gi < NG / GSTEP; ++gi) {
       const int g = gi * GSTEP;               // + g0 (in the lane bases)
@@ -353,6 +329,127 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
     }
   }
 
+  // D[row = co][col = pixel] + bias (+ residual) -> y   (WK: each wave stores a quarter of the registers)
+  // Same addressing scheme as the stagers: a wave-uniform base per tile, 32-bit lane byte offsets, the per-register
+  // channel step (a compile-time constant times H*W) on the scalar unit.
+  __device__ __forceinline__ static void epilogue(const acc_t (&acc)[MT][NT], const float* __restrict__ bias,
+                                                  const float* __restrict__ residual, float* __restrict__ y, const Shape& s,
+                                                  const TileCoord& tc, int co0, int pix0, int j, int h, int wave) {
+    const uint32_t HW = (uint32_t)(s.H * s.W);
+    const int64_t tile0 = ((((int64_t)tc.b0 * s.Cout + co0) * s.H + tc.h0) * s.W + tc.w0) * 4;
+    char* ybase = reinterpret_cast<char*>(y) + tile0;
+    const char* rbase = reinterpret_cast<const char*>(residual) + tile0;
+    const char* bbase = reinterpret_cast<const char*>(bias + co0);
+    const uint32_t lane_row = __umul24(4 * h, HW);
+    constexpr int NR = WK ? NREG / 4 : NREG;      // registers this wave stores per (m, n): WK waves take a quarter each
+    constexpr int NQ = WK ? 4 : 1;
+    auto row_of = [](int m, int r) { return m * MF + ((MF == 32) ? ((r & 3) + 8 * (r >> 2)) : r); };   // + 4*h
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) {
+      if (WK && qq != wave) continue;             // register indices stay compile-time constants
+      // All loads of a group are issued before the first use (one wait per group, not one per register): the bias
+      // values of this lane's rows first, then per pixel sub-tile the residual values, then the stores.
+      float bv[MT][NR];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) bv[m][k] = 0.f;
+      if (bias) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            const int row = min(row_of(m, qq * NR + k) + 4 * h, s.Cout - 1 - co0);     // clamped: always a valid address
+            bv[m][k] = *reinterpret_cast<const float*>(bbase + (uint32_t)(row << 2));
+          }
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int p = pix0 + n * MF + j;
+        const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
+        const int pr = rem / G::TW, pc = rem % G::TW;
+        if (tc.b0 + img >= s.B || tc.h0 + pr >= s.H || tc.w0 + pc >= s.W) continue;
+        const uint32_t lane_off = __umul24(__umul24(img, s.Cout), HW) + __umul24(pr, s.W) + pc + lane_row;
+        float o[MT][NR];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int k = 0; k < NR; ++k) o[m][k] = 0.f;
+        if (residual) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+              const int rc = row_of(m, qq * NR + k);
+              if (co0 + rc + 4 * h < s.Cout) o[m][k] = *reinterpret_cast<const float*>(rbase + ((lane_off + (uint32_t)rc * HW) << 2));
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            const int rc = row_of(m, qq * NR + k);
+            if (co0 + rc + 4 * h < s.Cout)
+              *reinterpret_cast<float*>(ybase + ((lane_off + (uint32_t)rc * HW) << 2)) = (acc[m][n][qq * NR + k] + bv[m][k]) + o[m][k];
+          }
+      }
+    }
+  }
+};
+
+// Waves per SIMD the register allocator is asked to fit (512 unified registers / SIMD lane): the 32-channel tiles sit
+// just above the 128-register line without the hint.
+template <class G, int KS, int MF, int MT> struct FwdOcc {   // (the multi-image 4x4 / 8x8 geometries would spill)
+  static constexpr int W = (KS == 3 && MF * MT == 32 && G::NI == 1 && G::NPIX == 256) ? 4 : 1;
+};
+
+template <class G, int KS, int MF, int MT, bool DGRAD>
+__global__ void __launch_bounds__(CT_THREADS, (FwdOcc<G, KS, MF, MT>::W))
+conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                const float* __restrict__ residual /*nullable, same shape as y*/, float* __restrict__ y, Shape s, int vec_x, int vec_w) {
+  using P = Patch<G, KS>;
+  constexpr bool WK = (G::NPIX == 64);        // waves split K (same pixels) instead of pixels
+  using Core = FwdCore<G, KS, MF, MT, WK>;
+  using WT = typename Core::WT;
+  constexpr int CT = Core::CT, KK = Core::KK, CK = Core::CK, CTS = Core::CTS, NT = Core::NT, KG = Core::KG, NREG = Core::NREG;
+  constexpr int STAGE = CK * P::CIS + WT::SIZE;
+  constexpr int REDF = WK ? 4 * MT * NT * NREG * 64 : 0;
+  __shared__ __attribute__((aligned(16))) float lds[STAGE > REDF ? STAGE : REDF];
+  float* pl = lds;
+  float* wl = lds + CK * P::CIS;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % MF, h = lane / MF;     // MF=32: h in {0,1}; MF=16: h in {0..3}
+  const TileCoord tc = decode_tile<G>(blockIdx.x, s.H, s.W);
+  const int co0 = blockIdx.y * CT;
+  const int pix0 = WK ? 0 : wave * 64;
+  const int g0 = WK ? wave : 0;
+
+  int lane_b[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) lane_b[n] = (h + g0 * KG) * P::CIS + pix_off<G, KS>(pix0 + n * MF + j);
+  const int lane_a = ((h + g0 * KG) * KK) * CTS + j;
+
+  typename Core::acc_t acc[MT][NT];
+  Core::zero(acc);
+
+  PatchStager<G, KS, CK> ps;
+  WeightStager<KS, CT, DGRAD, WK> ws;
+  ps.load(x, s, s.Cin, 0, tc, vec_x);
+  ws.load(w, s.Cin, s.Cout, 0, co0, vec_w);
+
+  for (int ci0 = 0; ci0 < s.Cin; ci0 += CK) {
+    __syncthreads();                          // every wave is done reading the previous chunk
+    ps.store(pl);
+    ws.store(wl);
+    __syncthreads();
+    if (ci0 + CK < s.Cin) {                   // next chunk's global loads fly under this chunk's MFMAs
+      ps.load(x, s, s.Cin, ci0 + CK, tc, vec_x);
+      ws.load(w, s.Cin, s.Cout, ci0 + CK, co0, vec_w);
+    }
+    Core::mfma_chunk(acc, pl, wl, lane_a, lane_b);
+  }
+
   if constexpr (WK) {
     // sum the four waves' partial accumulators through LDS (fixed order)
     __syncthreads();
@@ -375,31 +472,7 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
           acc[m][n][r] = (red[e] + red[PW_ + e]) + (red[2 * PW_ + e] + red[3 * PW_ + e]);
         }
   }
-
-  // epilogue: D[row = co][col = pixel]   (WK: each wave stores a quarter of the registers)
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int p = pix0 + n * MF + j;
-    const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
-    const int b = tc.b0 + img, hh = tc.h0 + rem / G::TW, ww = tc.w0 + rem % G::TW;
-    if (b >= s.B || hh >= s.H || ww >= s.W) continue;
-    const int64_t base = ((int64_t)b * s.Cout * s.H + hh) * s.W + ww;
-    const int64_t cstride = (int64_t)s.H * s.W;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-      for (int r = 0; r < NREG; ++r) {
-        if (WK && (r / (NREG / 4)) != wave) continue;
-        const int row = (MF == 32) ? ((r & 3) + 8 * (r >> 2) + 4 * h) : (h * 4 + r);
-        const int co = co0 + m * MF + row;
-        if (co < s.Cout) {
-          float o = acc[m][n][r] + (bias ? bias[co] : 0.f);
-          if (residual) o += residual[base + co * cstride];
-          y[base + co * cstride] = o;
-        }
-      }
-    }
-  }
+  Core::epilogue(acc, bias, residual, y, s, tc, co0, pix0, j, h, wave);
 }
 
 // =========================================================================== wgrad
@@ -721,6 +794,11 @@ static inline int check_shape(int B, int Cin, int Cout, int H, int W, int ks) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return TG_EINVAL;
   if (ks != 1 && ks != 3) return TG_EUNSUPPORTED;
   if ((int64_t)B * (Cin > Cout ? Cin : Cout) * H * W >= (1ll << 40)) return TG_EUNSUPPORTED;
+  // the kernels address with a 64-bit base per tile + 32-bit lane byte offsets built from 24-bit multiplies:
+  // a tile's image group (16 / 4 / 1 images for 4x4 / 8x8 / larger planes) must span < 2^30 elements
+  const int64_t ni = (H == 4 && W == 4) ? 16 : (H == 8 && W == 8) ? 4 : 1;
+  const int64_t cmax = Cin > Cout ? Cin : Cout;
+  if ((int64_t)H * W >= (1 << 24) || cmax * 9 >= (1 << 24) || ni * cmax * H * W >= (1ll << 30)) return TG_EUNSUPPORTED;
   return TG_OK;
 }
 

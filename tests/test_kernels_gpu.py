@@ -55,6 +55,9 @@ CONV_SHAPES = [
     (2, 3, 16, 40, 24, 1), (3, 128, 16, 16, 16, 1), (2, 100, 120, 8, 8, 3), (2, 8, 4, 32, 32, 3),
     (1, 4, 1, 16, 16, 1), (2, 16, 3, 20, 36, 3), (2, 32, 64, 32, 32, 1), (1, 64, 128, 16, 16, 1),
     (17, 16, 48, 4, 4, 1), (2, 32, 32, 128, 128, 3),
+    # many pixel tiles with a short reduction, ragged and aligned
+    (8, 16, 16, 128, 128, 3), (3, 5, 7, 250, 200, 3), (2, 32, 32, 256, 256, 3), (9, 20, 40, 96, 128, 3), (5, 24, 12, 130, 127, 3),
+    (8, 3, 16, 128, 128, 1), (8, 16, 3, 128, 128, 1), (4, 100, 33, 192, 128, 1), (33, 32, 16, 64, 64, 1),
 ]
 
 
