@@ -505,7 +505,9 @@ struct GyStager {
         const int img = t % G::NI, co = t / G::NI;
         const int b = tc.b0 + img, hh = tc.h0 + r, ww = tc.w0 + 4 * q;
         if (b < s.B && co0 + co < s.Cout && hh < s.H && ww < s.W) {
-          const float* src = gy + (((int64_t)b * s.Cout + co0 + co) * s.H + hh) * s.W + ww;
+          // wave-uniform tile base + 32-bit lane offset (see PatchStager)
+          const float* base = gy + ((((int64_t)tc.b0 * s.Cout + co0) * s.H + tc.h0) * s.W + tc.w0);
+          const float* src = base + (__umul24(__umul24(img, s.Cout) + co, s.H * s.W) + __umul24(r, s.W) + 4 * q);
           if (vec) {
             val = *reinterpret_cast<const float4*>(src);
           } else {
@@ -764,7 +766,8 @@ static inline WgPlan wgrad_plan(int B, int Cin, int Cout, int H, int W, int ks) 
   p.ci_chunks = (Cin + ckw - 1) / ckw;
   const int groups = p.co_tiles * p.ci_chunks;
   int S = 768 / groups;
-  if (S > 256) S = 256;
+  const int smax = p.tiles >= 4096 ? 512 : 256;      // measured: two workgroups per CU only pay off on the 128^2 planes
+  if (S > smax) S = smax;
   if (S < 1) S = 1;
   if (S > p.tiles) S = p.tiles;
   p.S = S;
