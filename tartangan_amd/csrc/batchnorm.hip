@@ -108,6 +108,50 @@ struct FwdBody {
   }
 };
 
+// statistics finished inside the apply pass (see planes::map_big_begin); arithmetic identical to stats_stage2
+struct FwdStatsBody {
+  const float* x; float* z;
+  const double* partial;
+  float *mean, *invstd, *rm, *rv;
+  int64_t* nbt;
+  const float *gamma, *beta;
+  float slope, momentum, eps;
+  int B, HW, S;
+  float a, b;
+  __device__ void begin(int c, bool lead) {
+    const double n = (double)B * HW;
+    const double pivot = (double)x[(int64_t)c * HW];
+    const double s1 = planes::gather(partial, c, S, 2, 0) / n;
+    const double s2 = planes::gather(partial, c, S, 2, 1) / n;
+    const double m = pivot + s1;
+    double var = s2 - s1 * s1;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+    a = gamma[c] * rf;
+    b = beta[c] - mf * a;
+    if (lead && threadIdx.x == 0) {
+      if (c == 0 && nbt != nullptr) *nbt += 1;
+      mean[c] = mf;
+      invstd[c] = rf;
+      if (rm != nullptr) {
+        const double unbiased = n > 1.0 ? var * (n / (n - 1.0)) : var;
+        rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * m);
+        rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
+      }
+    }
+  }
+  __device__ void vec4(int c, int64_t off) const {
+    const float4 v = *reinterpret_cast<const float4*>(x + off);
+    float4 r;
+    float y;
+    y = bn_y(v.x, a, b); r.x = y >= 0.f ? y : y * slope;
+    y = bn_y(v.y, a, b); r.y = y >= 0.f ? y : y * slope;
+    y = bn_y(v.z, a, b); r.z = y >= 0.f ? y : y * slope;
+    y = bn_y(v.w, a, b); r.w = y >= 0.f ? y : y * slope;
+    *reinterpret_cast<float4*>(z + off) = r;
+  }
+};
+
 // ------------------------------------------------------------------ first backward
 struct RedBwd {
   static constexpr int K = 2;
@@ -168,6 +212,42 @@ struct BwdBody {
   __device__ void one(int c, int64_t off) const {
     const float r = invstd[c], mu = mean[c], a = gamma[c] * r, b = beta[c] - mu * a;
     gx[off] = elem(gz[off], x[off], a, b, mu, r, coef[c * COEF + 0], coef[c * COEF + 1]);
+  }
+};
+
+// reduction finished inside the apply pass; arithmetic identical to bwd_stage2 + BwdBody
+struct BwdSumsBody {
+  const float *gz, *x; float* gx;
+  const double* partial;
+  const float *mean, *invstd, *gamma, *beta;
+  float *ggamma, *gbeta;
+  float slope; int training, accumulate, B, HW, S;
+  float a, b, mu, r, k1, k2;
+  __device__ void begin(int c, bool lead) {
+    const double n = (double)B * HW;
+    const double sb = planes::gather(partial, c, S, 2, 0);
+    const double sg = planes::gather(partial, c, S, 2, 1);
+    r = invstd[c]; mu = mean[c];
+    a = gamma[c] * r;
+    b = beta[c] - mu * a;
+    k1 = (float)(sb / n);
+    k2 = (float)(sg / n);
+    if (lead && threadIdx.x == 0) {
+      gbeta[c] = (float)sb + (accumulate ? gbeta[c] : 0.f);
+      ggamma[c] = (float)sg + (accumulate ? ggamma[c] : 0.f);
+    }
+  }
+  __device__ float elem(float g, float xv) const {
+    const float y = bn_y(xv, a, b);
+    const float gyh = y >= 0.f ? g : g * slope;
+    return training ? a * (gyh - k1 - ((xv - mu) * r) * k2) : a * gyh;
+  }
+  __device__ void vec4(int c, int64_t off) const {
+    const float4 g = *reinterpret_cast<const float4*>(gz + off);
+    const float4 v = *reinterpret_cast<const float4*>(x + off);
+    float4 o;
+    o.x = elem(g.x, v.x); o.y = elem(g.y, v.y); o.z = elem(g.z, v.z); o.w = elem(g.w, v.w);
+    *reinterpret_cast<float4*>(gx + off) = o;
   }
 };
 
@@ -458,6 +538,17 @@ int tg_bn_train_fwd(const float* x, float* mean, float* invstd, float* running_m
                                                             gamma, beta, slope, momentum, eps, z, B, C, HW);
     return tg_launch_status();
   }
+  if (planes::big(HW) && tg_aligned16(x) && tg_aligned16(z)) {
+    // two launches: the per-block partial sums, then the apply pass, whose blocks finish the reduction themselves
+    hipStream_t st = tg_stream(stream);
+    Parts p = split_ws(workspace, B, C, HW);
+    RedStats red{x, C, HW, 0.f};
+    planes::launch_reduce(red, p.partial, B, C, HW, st, true);
+    FwdStatsBody body{x, z, p.partial, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta,
+                      slope, momentum, eps, B, HW, planes::splits(B, C, HW), 0.f, 0.f};
+    planes::launch_map_begin(body, B, C, HW, st);
+    return tg_launch_status();
+  }
   if (int rc = tg_bn_train_stats(x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, workspace, B, C,
                                  HW, stream))
     return rc;
@@ -496,6 +587,12 @@ int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const floa
   Parts p = split_ws(workspace, B, C, HW);
   RedBwd red{gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
   planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz));
+  if (gx != nullptr && planes::big(HW) && tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx)) {
+    BwdSumsBody body{gz, x, gx, p.partial, mean, invstd, gamma, beta, ggamma, gbeta, slope, training, accumulate,
+                     B, HW, planes::splits(B, C, HW), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    planes::launch_map_begin(body, B, C, HW, st);
+    return tg_launch_status();
+  }
   bwd_stage2<<<C, 64, 0, st>>>(p.partial, ggamma, gbeta, p.coef, B, C, HW, planes::splits(B, C, HW), accumulate);
   if (gx != nullptr) {
     BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, training};

@@ -25,6 +25,24 @@ __global__ void __launch_bounds__(BLOCK) map_big(Body body, int C, int HW) {
   const int p = (blockIdx.y * BLOCK + threadIdx.x) * 4;
   if (p < HW) body.vec4(c, (int64_t)plane * HW + p);
 }
+// Same, for bodies whose per-channel constants come out of a stage-1 reduction: every block first finishes that
+// reduction for ITS channel (`begin`: a wave-parallel sum of the S partials, a few hundred bytes from L2) instead
+// of a separate one-wave-per-channel kernel between the two passes.  `lead` marks the one block per channel that
+// also publishes the per-channel results (statistics, parameter gradients).
+template <class Body>
+__global__ void __launch_bounds__(BLOCK) map_big_begin(Body body, int C, int HW) {
+  const int plane = blockIdx.x;
+  const int c = plane % C;
+  body.begin(c, plane == c && blockIdx.y == 0);
+  const int p = (blockIdx.y * BLOCK + threadIdx.x) * 4;
+  if (p < HW) body.vec4(c, (int64_t)plane * HW + p);
+}
+template <class Body>
+static inline void launch_map_begin(Body body, int B, int C, int HW, hipStream_t st) {   // big regime only
+  dim3 grid(B * C, (HW + TILE - 1) / TILE);
+  map_big_begin<Body><<<grid, BLOCK, 0, st>>>(body, C, HW);
+}
+
 template <class Body>
 __global__ void __launch_bounds__(BLOCK) map_flat(Body body, int C, int HW, int64_t total) {
   for (int64_t i = blockIdx.x * (int64_t)BLOCK + threadIdx.x; i < total; i += gridDim.x * (int64_t)BLOCK) {

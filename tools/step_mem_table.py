@@ -12,7 +12,7 @@ for _ in range(2): tr.train_batch(imgs)
 with bench.KernelTimer(K) as kt:
     tr.train_batch(imgs)
 torch.cuda.synchronize()
-PASSES = {'bn_train_stats': 1, 'bn_act_fwd': 2, 'bn_act_bwd': 5, 'bn_act_dbwd': 8, 'up2x': 1.25, 'pool2': 1.25, 'bilinear_half_fwd': 1.25,
+PASSES = {'bn_train_stats': 1, 'bn_train_fwd': 3, 'maxpool2_fwd': 1.25, 'maxpool2_bwd': 1.25, 'lrelu_bwd': 3, 'tanh_fwd': 2, 'tanh_bwd': 3, 'scale_add_dev': 3, 'scale_dev': 2, 'bn_act_fwd': 2, 'bn_act_bwd': 5, 'bn_act_dbwd': 8, 'up2x': 1.25, 'pool2': 1.25, 'bilinear_half_fwd': 1.25,
           'bilinear_half_bwd': 1.25, 'add': 3, 'channel_sum': 1}
 agg = collections.defaultdict(lambda: [0.0, 0, 0.0])
 for name, args, a, b in kt.records:
@@ -21,7 +21,7 @@ for name, args, a, b in kt.records:
     if name.startswith('bn_') or name == 'channel_sum':
         Bb, C, HW = ints[-4:-1] if name in ('bn_act_bwd', 'channel_sum') else ints[-3:]
         n = Bb * C * HW; key = (name, C, HW)
-    elif name == 'add':
+    elif name in ('add', 'lrelu_bwd', 'tanh_fwd', 'tanh_bwd', 'scale_add_dev', 'scale_dev'):
         n = ints[-1]; key = (name, n, 0)
     else:
         BC, H, W = ints[-3:]
