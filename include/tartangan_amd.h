@@ -54,6 +54,22 @@ size_t tg_conv2d_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ks)
 int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* gbias /*nullable*/,
                     float* workspace, size_t workspace_bytes,
                     int B, int Cin, int Cout, int H, int W, int ks, int accumulate, void* stream);
+/* The same in two steps, so that ONE launch can finish the reduction for many layers (a whole backward pass):
+ *   tg_conv2d_wgrad_partials     stage 1 only: per-workgroup partial sums into `workspace` (which must then stay
+ *                                untouched until the batch reduce has run);
+ *   tg_conv2d_wgrad_reduce_batch stage 2 for n_items layers.  `items` is a HOST array of
+ *                                n_items x TG_WGRAD_ITEM_FIELDS 64-bit words:
+ *                                  [0] workspace (device address)   [1] gw (device address)
+ *                                  [2] gbias (device address or 0; nonzero needs want_bias != 0 in stage 1)
+ *                                  [3..8] B, Cin, Cout, H, W, ks     [9] accumulate
+ * Results are bit-identical to tg_conv2d_wgrad (same partials, same summation order).  Within one call every
+ * gw / gbias may appear at most once (items are reduced concurrently); further contributions to the same
+ * gradient go into a later call.                                                                           */
+typedef int64_t tg_host_i64;
+#define TG_WGRAD_ITEM_FIELDS 10
+int tg_conv2d_wgrad_partials(const float* x, const float* gy, float* workspace, size_t workspace_bytes,
+                             int B, int Cin, int Cout, int H, int W, int ks, int want_bias, void* stream);
+int tg_conv2d_wgrad_reduce_batch(const tg_host_i64* items /*host*/, int n_items, void* stream);
 /* out[c] (+)= sum_{b,p} x[b][c][p]   (linear bias grad); workspace: tg_bn_workspace(B,C,HW) bytes */
 int tg_channel_sum(const float* x, float* out, float* workspace, int B, int C, int HW, int accumulate,
                    void* stream);

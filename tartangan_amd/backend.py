@@ -24,6 +24,7 @@ _CTYPES = {
     'const uint8_t*': ctypes.c_void_p, 'uint8_t*': ctypes.c_void_p, 'int64_t*': ctypes.c_void_p,
     'void*': ctypes.c_void_p, 'int': ctypes.c_int, 'int64_t': ctypes.c_int64,
     'size_t': ctypes.c_size_t, 'float': ctypes.c_float, 'const char*': ctypes.c_char_p,
+    'const tg_host_i64*': ctypes.c_void_p,          # HOST array (a CPU int64 tensor), not a device pointer
 }
 
 
@@ -82,6 +83,11 @@ class HipBackend:
             for i in ptr_pos:
                 t = args[i]
                 if t is None:
+                    continue
+                if 'tg_host' in params[i][0]:
+                    if t.is_cuda or t.dtype != torch.int64 or not t.is_contiguous():
+                        raise RuntimeError(f'{name}: argument {params[i][1]} must be a contiguous CPU int64 tensor')
+                    args[i] = t.data_ptr()
                     continue
                 if not t.is_cuda:
                     raise RuntimeError(f'{name}: argument {params[i][1]} is not on a ROCm device '

@@ -652,18 +652,18 @@ conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, flo
 // gw[e] (+)= sum_s part[s][e], fixed order.  64 consecutive e per workgroup (coalesced), the S partials
 // are split over the 4 waves and combined through LDS: no serial chain of S dependent loads.
 // Workgroups past ceil(E/64) reduce the bias partials the same way.
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int64_t E, int S,
-                                                           const float* __restrict__ bias_part, float* __restrict__ gbias, int Cout,
-                                                           int accumulate) {
+__device__ __forceinline__ void wgrad_reduce_block(int blk, const float* __restrict__ part, float* __restrict__ gw, int64_t E, int S,
+                                                   const float* __restrict__ bias_part, float* __restrict__ gbias, int Cout,
+                                                   int accumulate) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int eblocks = (int)((E + 63) / 64);
   const float* src = part;
   float* dst = gw;
-  int64_t n = E, e = blockIdx.x * 64ll + lane;
-  if ((int)blockIdx.x >= eblocks) {
+  int64_t n = E, e = blk * 64ll + lane;
+  if (blk >= eblocks) {
     src = bias_part; dst = gbias; n = Cout;
-    e = (blockIdx.x - eblocks) * 64ll + lane;
+    e = (blk - eblocks) * 64ll + lane;
   }
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (e < n) {
@@ -682,6 +682,36 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     const float r = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     dst[e] = accumulate ? dst[e] + r : r;
   }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int64_t E, int S,
+                                                           const float* __restrict__ bias_part, float* __restrict__ gbias, int Cout,
+                                                           int accumulate) {
+  wgrad_reduce_block(blockIdx.x, part, gw, E, S, bias_part, gbias, Cout, accumulate);
+}
+
+// The same reduction for MANY layers in one launch (a whole backward pass' worth of partials): the per-layer
+// reduce is ~5 us of launch latency for ~1 us of work, ~100 times per training step.  Items travel in the kernel
+// argument block (no table in memory to keep alive or copy), a workgroup finds its item by scanning <= MAX_ITEMS
+// block offsets.
+constexpr int RB_MAX_ITEMS = 40;
+struct ReduceItem {
+  const float* part; float* gw; float* gbias;   // gbias null: no bias gradient; bias partials sit at part + S*E
+  int64_t E;
+  int S, Cout, accumulate, pad;
+};
+struct ReduceBatch {
+  int n;
+  int block_end[RB_MAX_ITEMS];                  // exclusive prefix of workgroups per item
+  ReduceItem item[RB_MAX_ITEMS];
+};
+__global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(ReduceBatch rb) {
+  int i = 0;
+  while (i + 1 < rb.n && (int)blockIdx.x >= rb.block_end[i]) ++i;     // uniform per workgroup
+  const ReduceItem it = rb.item[i];
+  const int blk = blockIdx.x - (i > 0 ? rb.block_end[i - 1] : 0);
+  wgrad_reduce_block(blk, it.part, it.gw, it.E, it.S, it.gbias ? it.part + (int64_t)it.S * it.E : nullptr, it.gbias, it.Cout,
+                     it.accumulate);
 }
 
 // =========================================================================== host dispatch
@@ -833,20 +863,67 @@ size_t tg_conv2d_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ks)
   return ((size_t)p.S * Cout * Cin * ks * ks + (size_t)p.S * Cout) * sizeof(float);
 }
 
-int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* gbias, float* workspace, size_t workspace_bytes, int B,
-                    int Cin, int Cout, int H, int W, int ks, int accumulate, void* stream) {
-  TG_CHECK_PTR(x); TG_CHECK_PTR(gy); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
+static int wgrad_partials(const float* x, const float* gy, float* workspace, size_t workspace_bytes, int B, int Cin, int Cout, int H,
+                          int W, int ks, int want_bias, hipStream_t st, WgPlan* plan) {
   if (int rc = check_shape(B, Cin, Cout, H, W, ks)) return rc;
   if (workspace_bytes < tg_conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks)) return TG_EWORKSPACE;
   const WgPlan p = wgrad_plan(B, Cin, Cout, H, W, ks);
   Shape s{B, Cin, Cout, H, W};
+  const int64_t E = (int64_t)Cout * Cin * ks * ks;
+  float* bias_part = want_bias ? workspace + (size_t)p.S * E : nullptr;
+  *plan = p;
+  return ks == 3 ? launch_wgrad<3>(x, gy, workspace, bias_part, s, p, st) : launch_wgrad<1>(x, gy, workspace, bias_part, s, p, st);
+}
+
+int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* gbias, float* workspace, size_t workspace_bytes, int B,
+                    int Cin, int Cout, int H, int W, int ks, int accumulate, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(gy); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
   hipStream_t st = tg_stream(stream);
+  WgPlan p;
+  if (int rc = wgrad_partials(x, gy, workspace, workspace_bytes, B, Cin, Cout, H, W, ks, gbias != nullptr, st, &p)) return rc;
   const int64_t E = (int64_t)Cout * Cin * ks * ks;
   float* bias_part = gbias ? workspace + (size_t)p.S * E : nullptr;
-  const int rc = ks == 3 ? launch_wgrad<3>(x, gy, workspace, bias_part, s, p, st) : launch_wgrad<1>(x, gy, workspace, bias_part, s, p, st);
-  if (rc != TG_OK) return rc;
   const int blocks = (int)((E + 63) / 64) + (gbias ? (Cout + 63) / 64 : 0);
   wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(workspace, gw, E, p.S, bias_part, gbias, Cout, accumulate);
+  return tg_launch_status();
+}
+
+int tg_conv2d_wgrad_partials(const float* x, const float* gy, float* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
+                             int H, int W, int ks, int want_bias, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(gy); TG_CHECK_PTR(workspace);
+  WgPlan p;
+  return wgrad_partials(x, gy, workspace, workspace_bytes, B, Cin, Cout, H, W, ks, want_bias, tg_stream(stream), &p);
+}
+
+int tg_conv2d_wgrad_reduce_batch(const tg_host_i64* items, int n_items, void* stream) {
+  if (n_items < 0) return TG_EINVAL;
+  if (n_items == 0) return TG_OK;
+  TG_CHECK_PTR(items);
+  hipStream_t st = tg_stream(stream);
+  for (int base = 0; base < n_items; base += RB_MAX_ITEMS) {
+    ReduceBatch rb;
+    rb.n = n_items - base < RB_MAX_ITEMS ? n_items - base : RB_MAX_ITEMS;
+    int blocks = 0;
+    for (int i = 0; i < rb.n; ++i) {
+      const tg_host_i64* it = items + (size_t)(base + i) * TG_WGRAD_ITEM_FIELDS;
+      const int B = (int)it[3], Cin = (int)it[4], Cout = (int)it[5], H = (int)it[6], W = (int)it[7], ks = (int)it[8];
+      if (it[0] == 0 || it[1] == 0) return TG_EINVAL;
+      if (int rc = check_shape(B, Cin, Cout, H, W, ks)) return rc;
+      ReduceItem& r = rb.item[i];
+      r.part = reinterpret_cast<const float*>(it[0]);
+      r.gw = reinterpret_cast<float*>(it[1]);
+      r.gbias = reinterpret_cast<float*>(it[2]);
+      r.E = (int64_t)Cout * Cin * ks * ks;
+      r.S = wgrad_plan(B, Cin, Cout, H, W, ks).S;
+      r.Cout = Cout;
+      r.accumulate = (int)it[9];
+      r.pad = 0;
+      blocks += (int)((r.E + 63) / 64) + (r.gbias ? (Cout + 63) / 64 : 0);
+      rb.block_end[i] = blocks;
+    }
+    for (int i = rb.n; i < RB_MAX_ITEMS; ++i) rb.block_end[i] = blocks;
+    wgrad_reduce_batch_kernel<<<blocks, 256, 0, st>>>(rb);
+  }
   return tg_launch_status();
 }
 

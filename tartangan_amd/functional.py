@@ -13,6 +13,8 @@ Linear ops come as transpose pairs (each is the other's backward):
   transpose;  maxpool scatter <-> gather;  row_sum <-> row_bcast;
   repeat_rows <-> sum_reps;  channel_sum <-> channel_bcast.
 """
+import contextlib
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -105,10 +107,66 @@ class _ConvDgrad(Function):
         return a_gy, a_w
 
 
+class _DeferredWgrad:
+    """State of ``deferred_wgrad()``: rows of the batch-reduce table + the partial-sum buffers they point at."""
+    active = False
+    items = []
+    keep = []
+
+
+@contextlib.contextmanager
+def deferred_wgrad():
+    """Batch the second stage of every conv weight gradient that accumulates straight into ``.grad``.
+
+    A backward pass runs ~30-50 weight-gradient kernels, each followed by a reduction of its per-workgroup partials
+    that is ~1 us of work behind ~5 us of launch latency.  Inside this context the reductions are recorded instead
+    and run as ONE launch on exit (``tg_conv2d_wgrad_reduce_batch``; same partials, same summation order, so
+    bit-identical gradients).  Only the trainers use it, around their own ``backward`` calls: until the context
+    exits the ``.grad`` of conv weights is incomplete, which a foreign training loop could not know.
+    """
+    outer = _DeferredWgrad.active
+    _DeferredWgrad.active = True
+    try:
+        yield
+    finally:
+        _DeferredWgrad.active = outer
+        if not outer:
+            flush_wgrad()
+
+
+def flush_wgrad():
+    st = _DeferredWgrad
+    if st.items:
+        items, st.items = st.items, []
+        try:
+            # A weight that collected several contributions in this pass (the discriminator sees the real and the
+            # fake batch) must not be updated by two workgroups of one launch: contribution k of every weight goes
+            # into launch k, in recording order (= the order the per-layer calls would have accumulated in).
+            rounds, seen = [], {}
+            for row in items:
+                k = seen.get(row[1], 0)
+                seen[row[1]] = k + 1
+                if k == len(rounds):
+                    rounds.append([])
+                rounds[k].append(row)
+            for rows in rounds:
+                K().conv2d_wgrad_reduce_batch(torch.tensor(rows, dtype=torch.int64), len(rows))
+        finally:
+            st.keep = []
+
+
 def _conv_wgrad_into(x, gy, gw, gbias, ks, accumulate):
     B, Cin, H, W = x.shape
     Cout = gy.shape[1]
-    ws = _ws(x, K().conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks))
+    nbytes = K().conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks)
+    if accumulate and _DeferredWgrad.active:
+        ws = x.new_empty(nbytes // 4 + 4)               # its own buffer: must survive until the batch reduce
+        K().conv2d_wgrad_partials(x, gy, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks, int(gbias is not None))
+        _DeferredWgrad.items.append([ws.data_ptr(), gw.data_ptr(), gbias.data_ptr() if gbias is not None else 0,
+                                     B, Cin, Cout, H, W, ks, 1])
+        _DeferredWgrad.keep.append((ws, gw, gbias))
+        return
+    ws = _ws(x, nbytes)
     K().conv2d_wgrad(x, gy, gw, gbias, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks, accumulate)
 
 

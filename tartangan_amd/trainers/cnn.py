@@ -91,7 +91,8 @@ class CNNTrainer(Trainer):
             d_loss = TF.add(d_loss, d_grad_penalty)
         # same parameter gradients as d_loss.backward(); naming the leaves just spares autograd the gradient
         # w.r.t. the real images, which the reference computes (real.requires_grad_) and never reads
-        torch.autograd.backward(d_loss, inputs=[p for p in self.d.parameters() if p.requires_grad])
+        with TF.deferred_wgrad():       # one launch finishes all conv weight-gradient reductions of this pass
+            torch.autograd.backward(d_loss, inputs=[p for p in self.d.parameters() if p.requires_grad])
         return d_loss.detach(), (d_grad_penalty.detach() if d_grad_penalty is not None else None)
 
     def _g_phase(self, bs):
@@ -101,7 +102,8 @@ class CNNTrainer(Trainer):
         self.optimizer_g.zero_grad()
         fake = self.sample_g(bs)
         g_loss = self._g_loss(fake, torch.ones(bs, 1, device=self.device))
-        g_loss.backward()
+        with TF.deferred_wgrad():
+            g_loss.backward()
         return g_loss.detach()
 
     def train_batch(self, imgs):

@@ -33,7 +33,34 @@ class Emulator:
         return 0
 
     def conv2d_wgrad_workspace(self, B, Cin, Cout, H, W, ks):
-        return 16
+        return (Cout * Cin * ks * ks + Cout) * 4        # room for one "partial" of the weight and the bias gradient
+
+    def conv2d_wgrad_partials(self, x, gy, ws, ws_bytes, B, Cin, Cout, H, W, ks, want_bias):
+        E = Cout * Cin * ks * ks
+        assert ws_bytes >= (E + Cout) * 4
+        ws[:E].copy_(torch.nn.grad.conv2d_weight(_v(x, B, Cin, H, W), (Cout, Cin, ks, ks), _v(gy, B, Cout, H, W),
+                                                 padding=ks // 2).reshape(-1))
+        if want_bias:
+            ws[E:E + Cout].copy_(_v(gy, B, Cout, H * W).sum((0, 2)))
+        return 0
+
+    def conv2d_wgrad_reduce_batch(self, items, n_items):
+        import ctypes
+        import numpy as np
+
+        def at(addr, n):          # a float32 view of host memory (every tensor is a CPU tensor under the emulator)
+            return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(addr)))
+
+        assert items.dtype == torch.int64 and tuple(items.shape) == (n_items, 10)
+        for part, gw, gbias, B, Cin, Cout, H, W, ks, accumulate in items.tolist():
+            E = Cout * Cin * ks * ks
+            dst = at(gw, E)
+            dst.copy_(dst + at(part, E) if accumulate else at(part, E))
+            if gbias:
+                dstb = at(gbias, Cout)
+                src = at(part + 4 * E, Cout)
+                dstb.copy_(dstb + src if accumulate else src)
+        return 0
 
     def conv2d_wgrad(self, x, gy, gw, gbias, ws, ws_bytes, B, Cin, Cout, H, W, ks, accumulate):
         r = torch.nn.grad.conv2d_weight(_v(x, B, Cin, H, W), (Cout, Cin, ks, ks), _v(gy, B, Cout, H, W), padding=ks // 2)

@@ -115,6 +115,34 @@ def test_conv_wgrad_is_deterministic(K):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
+def test_conv_wgrad_batched_reduce_is_bit_identical(K):
+    """stage 1 + one batched stage 2 over many layers == the per-layer call, bit for bit (also across the
+    kernel-argument chunking at 40 items)."""
+    shapes = [(4, 16, 16, 32, 32, 3), (2, 128, 128, 8, 8, 3), (3, 5, 7, 20, 12, 3), (4, 32, 4, 32, 32, 1), (2, 3, 16, 64, 64, 1)] * 9
+    want, got, items, keep = [], [], [], []
+    for i, (B, Cin, Cout, H, W, ks) in enumerate(shapes):
+        x, gy = rnd(B, Cin, H, W, seed=i).cuda(), rnd(B, Cout, H, W, seed=100 + i).cuda()
+        bias = i % 2 == 0
+        gw0, gb0 = rnd(Cout, Cin, ks, ks, seed=200 + i).cuda(), rnd(Cout, seed=300 + i).cuda()
+        nbytes = K.conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks)
+        ws = torch.zeros(nbytes // 4 + 4).cuda()
+        a, ab = gw0.clone(), gb0.clone()
+        K.conv2d_wgrad(x, gy, a, ab if bias else None, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks, 1)
+        want.append((a, ab))
+        b, bb = gw0.clone(), gb0.clone()
+        ws2 = torch.zeros(nbytes // 4 + 4).cuda()
+        K.conv2d_wgrad_partials(x, gy, ws2, ws2.numel() * 4, B, Cin, Cout, H, W, ks, int(bias))
+        items.append([ws2.data_ptr(), b.data_ptr(), bb.data_ptr() if bias else 0, B, Cin, Cout, H, W, ks, 1])
+        got.append((b, bb))
+        keep.append(ws2)
+    K.conv2d_wgrad_reduce_batch(torch.tensor(items, dtype=torch.int64), len(items))
+    torch.cuda.synchronize()
+    for (a, ab), (b, bb) in zip(want, got):
+        assert torch.equal(a, b) and torch.equal(ab, bb)
+    with pytest.raises(RuntimeError):
+        K.conv2d_wgrad_reduce_batch(torch.tensor(items, dtype=torch.int64).cuda(), len(items))    # table must be host memory
+
+
 def test_conv_rejects_unsupported(K):
     x = torch.zeros(1, 4, 8, 8).cuda()
     with pytest.raises(RuntimeError):
