@@ -771,11 +771,12 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, const floa
 
 template <int KS, bool DGRAD>
 int launch_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
-  // small layers: if 256-pixel tiles give fewer than ~2 workgroups per CU, use 64-pixel tiles whose
-  // waves split K (4x the workgroups, each wave 1/4 of the k-groups)
+  // small layers: if 256-pixel tiles cannot even give every other CU a workgroup, use 64-pixel tiles whose waves
+  // split K (4x the workgroups, each wave 1/4 of the k-groups).  Measured at batch 64: 128->128 @ 16^2 (128
+  // such workgroups) runs 65 us unsplit vs 74 us split; @ 8^2 (32) 55 us vs 24 us.
   const GeoId g = pick_geo(s.H, s.W);
   const int64_t wgs256 = (int64_t)geo_tiles(g, s.B, s.H, s.W) * ((s.Cout + 63) / 64);
-  const bool ksplit = (g != GEO_X) && wgs256 < 512 && s.Cin >= 16;
+  const bool ksplit = (g != GEO_X) && wgs256 < 128 && s.Cin >= 16;
   switch (g) {
     case GEO_4: return ksplit ? launch_fwd_geo<G4k, KS, DGRAD>(x, w, bias, residual, y, s, st) : launch_fwd_geo<G4, KS, DGRAD>(x, w, bias, residual, y, s, st);
     case GEO_8: return ksplit ? launch_fwd_geo<G8k, KS, DGRAD>(x, w, bias, residual, y, s, st) : launch_fwd_geo<G8, KS, DGRAD>(x, w, bias, residual, y, s, st);
