@@ -135,9 +135,11 @@ int tg_up2x(const float* x, float* y, float alpha, int BC, int H, int W, void* s
 int tg_pool2(const float* x, const float* residual /*nullable: y = residual + pooled (discriminator.py:95)*/,
              float* y, float alpha, int BC, int H, int W, void* stream);
 /* F.interpolate(scale_factor=0.5, mode='bilinear', align_corners=True) discriminator.py:55-57
- * input HxW -> output floor(H/2) x floor(W/2); _bwd is its transpose (scatter-free gather form) */
+ * input HxW -> output floor(H/2) x floor(W/2); _bwd is its transpose (scatter-free gather form), optionally
+ * added to `residual` (the gradient that reached the same tensor through the block's main path) */
 int tg_bilinear_half_fwd(const float* x, float* y, int BC, int H, int W, void* stream);
-int tg_bilinear_half_bwd(const float* gy, float* gx, int BC, int H, int W, void* stream);
+int tg_bilinear_half_bwd(const float* gy, const float* residual /*nullable, shape of gx*/, float* gx,
+                         int BC, int H, int W, void* stream);
 /* F.max_pool2d(x,[2,2]) attention.py:25-26; idx = argmax position 0..3 inside the window
  * (first maximum in row-major window order, like ATen)                          */
 int tg_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int BC, int H, int W, void* stream);

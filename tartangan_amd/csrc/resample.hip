@@ -113,8 +113,8 @@ __device__ __forceinline__ float axis_weight(int o, int in, float scale, int in_
   return w;
 }
 
-__global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                                     int64_t nin, int H, int W, int OH, int OW, float sh, float sw) {
+__global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ residual,
+                                                                     float* __restrict__ gx, int64_t nin, int H, int W, int OH, int OW, float sh, float sw) {
   for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < nin; i += gridDim.x * (int64_t)RS_BLOCK) {
     const int w = (int)(i % W);
     const int64_t t = i / W;
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_kernel(const float
         if (ww[t2] != 0.f) racc += ww[t2] * g[(oh_lo + u) * OW + ow_lo + t2];
       acc += wh[u] * racc;
     }
-    gx[i] = acc;
+    gx[i] = residual ? residual[i] + acc : acc;
   }
 }
 
@@ -150,7 +150,8 @@ __global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_kernel(const float
 // (H + W entries instead of 8 index evaluations per element) and the gy plane is read from LDS.
 constexpr int BL_MAX_OUT = 8192;     // OH*OW floats of gy staged in LDS (32 KB)
 struct AxisEntry { int lo; float w[4]; };
-__global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_plane_kernel(const float* __restrict__ gy, float* __restrict__ gx, int BC,
+__global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_plane_kernel(const float* __restrict__ gy, const float* __restrict__ residual,
+                                                                           float* __restrict__ gx, int BC,
                                                                            int H, int W, int OH, int OW, float sh, float sw) {
   __shared__ float g[BL_MAX_OUT];
   __shared__ AxisEntry rows[128], cols[128];
@@ -174,6 +175,7 @@ __global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_plane_kernel(const
     for (int i = threadIdx.x; i < nout; i += RS_BLOCK) g[i] = gp[i];
     __syncthreads();
     float* xp = gx + (int64_t)plane * nin;
+    const float* rp = residual ? residual + (int64_t)plane * nin : nullptr;
     for (int i = threadIdx.x; i < nin; i += RS_BLOCK) {
       const int h = i / W, w = i - h * W;
       const AxisEntry r = rows[h], c = cols[w];
@@ -188,7 +190,7 @@ __global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_plane_kernel(const
           if (c.w[t] != 0.f) racc += c.w[t] * grow[t];
         acc += r.w[u] * racc;
       }
-      xp[i] = acc;
+      xp[i] = rp ? rp[i] + acc : acc;
     }
   }
 }
@@ -286,18 +288,18 @@ int tg_bilinear_half_fwd(const float* x, float* y, int BC, int H, int W, void* s
   return tg_launch_status();
 }
 
-int tg_bilinear_half_bwd(const float* gy, float* gx, int BC, int H, int W, void* stream) {
+int tg_bilinear_half_bwd(const float* gy, const float* residual, float* gx, int BC, int H, int W, void* stream) {
   TG_CHECK_PTR(gy); TG_CHECK_PTR(gx); TG_CHECK_POS(BC);
   if (H < 2 || W < 2) return TG_EUNSUPPORTED;
   const int OH = H / 2, OW = W / 2;
   const int64_t nin = (int64_t)BC * H * W;
   if (H <= 128 && W <= 128 && OH * OW <= BL_MAX_OUT && H * W >= 256) {
     const int grid = BC < 2048 ? BC : 2048;
-    bilinear_half_bwd_plane_kernel<<<grid, RS_BLOCK, 0, tg_stream(stream)>>>(gy, gx, BC, H, W, OH, OW, ac_scale(H, OH),
+    bilinear_half_bwd_plane_kernel<<<grid, RS_BLOCK, 0, tg_stream(stream)>>>(gy, residual, gx, BC, H, W, OH, OW, ac_scale(H, OH),
                                                                              ac_scale(W, OW));
     return tg_launch_status();
   }
-  bilinear_half_bwd_kernel<<<tg_ew_grid(nin, RS_BLOCK), RS_BLOCK, 0, tg_stream(stream)>>>(gy, gx, nin, H, W, OH, OW,
+  bilinear_half_bwd_kernel<<<tg_ew_grid(nin, RS_BLOCK), RS_BLOCK, 0, tg_stream(stream)>>>(gy, residual, gx, nin, H, W, OH, OW,
                                                                                          ac_scale(H, OH), ac_scale(W, OW));
   return tg_launch_status();
 }

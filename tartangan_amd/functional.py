@@ -445,17 +445,75 @@ class _BilinearHalf(Function):
 
 
 class _BilinearHalfT(Function):
+    """transpose of the bilinear x0.5 map [+ residual]"""
+
     @staticmethod
-    def forward(ctx, gy, hw):
+    def forward(ctx, gy, hw, residual=None):
         gy = gy.contiguous()
         B, C = gy.shape[:2]
         gx = gy.new_empty(B, C, hw[0], hw[1])
-        K().bilinear_half_bwd(gy, gx, B * C, hw[0], hw[1])
+        if residual is not None:
+            residual = residual.contiguous()
+        K().bilinear_half_bwd(gy, residual, gx, B * C, hw[0], hw[1])
+        ctx.has_residual = residual is not None
         return gx
 
     @staticmethod
     def backward(ctx, v):
-        return _BilinearHalf.apply(v), None
+        return _BilinearHalf.apply(v), None, (v if ctx.has_residual and ctx.needs_input_grad[2] else None)
+
+
+class _ForkBilinearHalf(Function):
+    """x -> (bilinear_half(x), x): the two uses of a discriminator block's input (shortcut and main path) as ONE graph
+    node, so that its backward sees both incoming gradients and can add them inside the transpose kernel instead of
+    leaving a separate full-resolution add to the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = x.new_empty(B, C, H // 2, W // 2)
+        K().bilinear_half_fwd(x, y, B * C, H, W)
+        ctx.hw = (H, W)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_half, g_pass):
+        if g_half is None:
+            return g_pass
+        return _BilinearHalfT.apply(g_half, ctx.hw, g_pass)
+
+
+class _ForkUp2x(Function):
+    """x -> (up2x(x), up2x(x)) (one tensor, two graph edges): the generator block's upsampled input feeds the shortcut
+    and the main path; backward pools both incoming gradients without first adding them at the high resolution."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = x.new_empty(B, C, 2 * H, 2 * W)
+        K().up2x(x, y, 1.0, B * C, H, W)
+        ctx.set_materialize_grads(False)
+        return y, y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            g = ga if gb is None else gb
+            return None if g is None else _Pool2.apply(g, 1.0)
+        return _Pool2.apply(ga, 1.0, _Pool2.apply(gb, 1.0))
+
+
+def fork_bilinear_half(x):
+    """-> (F.interpolate(x, scale_factor=0.5, mode='bilinear', align_corners=True), x)"""
+    return _ForkBilinearHalf.apply(x)
+
+
+def fork_upsample_nearest2x(x):
+    """-> (up, up) with up = F.interpolate(x, scale_factor=2), for two consumers"""
+    return _ForkUp2x.apply(x)
 
 
 def bilinear_half(x):

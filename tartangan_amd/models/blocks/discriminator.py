@@ -51,7 +51,10 @@ class ResidualDiscriminatorBlock(nn.Module):
         self.interpolate = interpolate
 
     def forward(self, x):
-        shortcut = self.interpolate(x)
+        if self.interpolate is _half:
+            shortcut, x = TF.fork_bilinear_half(x)      # one graph node for both uses of x (see functional._ForkBilinearHalf)
+        else:
+            shortcut = self.interpolate(x)
         if self.project_input is not None:
             shortcut = run_layers(self.project_input, shortcut)
         return run_layers(self.convs, x, residual=shortcut)          # x + h, the add fused into the avg-pool

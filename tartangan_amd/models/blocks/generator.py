@@ -36,9 +36,10 @@ class ResidualGeneratorBlock(nn.Module):
         self.convs = nn.Sequential(*body)
 
     def forward(self, x):
+        xs = x
         if self.upsample:
-            x = TF.upsample_nearest2x(x)
-        shortcut = x if self.project_input is None else run_layers(self.project_input, x)
+            xs, x = TF.fork_upsample_nearest2x(x)        # one graph node for both uses (functional._ForkUp2x)
+        shortcut = xs if self.project_input is None else run_layers(self.project_input, xs)
         return run_layers(self.convs, x, residual=shortcut)          # x + h, the add fused into the last conv
 
 

@@ -193,12 +193,12 @@ class Emulator:
                                                       align_corners=True)[0])
         return 0
 
-    def bilinear_half_bwd(self, gy, gx, BC, H, W):
+    def bilinear_half_bwd(self, gy, residual, gx, BC, H, W):
         with torch.enable_grad():
             xin = torch.zeros(1, BC, H, W, requires_grad=True)
             out = F.interpolate(xin, scale_factor=0.5, mode='bilinear', align_corners=True)
             g, = torch.autograd.grad(out, xin, _v(gy, 1, BC, H // 2, W // 2).detach())
-        _v(gx, BC, H, W).copy_(g[0])
+        _v(gx, BC, H, W).copy_(g[0] if residual is None else _v(residual, BC, H, W) + g[0])
         return 0
 
     def maxpool2_fwd(self, x, y, idx, BC, H, W):

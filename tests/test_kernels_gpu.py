@@ -190,7 +190,8 @@ def test_resample(K, shape):
         run_both(K, 'pool2', [x, None, torch.zeros(BC, H // 2, W // 2), alpha, BC, H, W], [2], tol=1e-6)
         run_both(K, 'pool2', [x, rnd(BC, H // 2, W // 2, seed=3), torch.zeros(BC, H // 2, W // 2), alpha, BC, H, W], [2], tol=1e-6)
     run_both(K, 'bilinear_half_fwd', [x, torch.zeros(BC, H // 2, W // 2), BC, H, W], [1], tol=1e-5)   # lambda = r - floor(r) carries ulp(r)
-    run_both(K, 'bilinear_half_bwd', [rnd(BC, H // 2, W // 2), torch.zeros(BC, H, W), BC, H, W], [1], tol=1e-5)
+    run_both(K, 'bilinear_half_bwd', [rnd(BC, H // 2, W // 2), None, torch.zeros(BC, H, W), BC, H, W], [2], tol=1e-5)
+    run_both(K, 'bilinear_half_bwd', [rnd(BC, H // 2, W // 2), rnd(BC, H, W, seed=5), torch.zeros(BC, H, W), BC, H, W], [2], tol=1e-5)
     idx = torch.zeros(BC, H // 2, W // 2, dtype=torch.uint8)
     run_both(K, 'maxpool2_fwd', [x, torch.zeros(BC, H // 2, W // 2), idx, BC, H, W], [1, 2], atol=0.0)
     E.maxpool2_fwd(x, torch.zeros(BC, H // 2, W // 2), idx, BC, H, W)

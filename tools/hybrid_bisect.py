@@ -89,7 +89,7 @@ y_hip = torch.zeros(12, 64, 64).cuda(); HIP.bilinear_half_fwd(x.cuda(), y_hip, 1
 y64 = torch.nn.functional.interpolate(x.double()[None], scale_factor=0.5, mode='bilinear', align_corners=True)[0]
 print('bilinear fwd 128: hip-vs-cpu32 %.2e  hip-vs-f64 %.2e  cpu32-vs-f64 %.2e' % (float((y_hip.cpu() - y_cpu).abs().max()), float((y_hip.cpu().double() - y64).abs().max()), float((y_cpu.double() - y64).abs().max())))
 g = torch.randn(12, 64, 64)
-gx_cpu = torch.zeros(12, 128, 128); EMU.bilinear_half_bwd(g, gx_cpu, 12, 128, 128)
-gx_hip = torch.zeros(12, 128, 128).cuda(); HIP.bilinear_half_bwd(g.cuda(), gx_hip, 12, 128, 128)
-gx64 = torch.zeros(12, 128, 128, dtype=torch.float64); EMU.bilinear_half_bwd(g.double(), gx64, 12, 128, 128)
+gx_cpu = torch.zeros(12, 128, 128); EMU.bilinear_half_bwd(g, None, gx_cpu, 12, 128, 128)
+gx_hip = torch.zeros(12, 128, 128).cuda(); HIP.bilinear_half_bwd(g.cuda(), None, gx_hip, 12, 128, 128)
+gx64 = torch.zeros(12, 128, 128, dtype=torch.float64); EMU.bilinear_half_bwd(g.double(), None, gx64, 12, 128, 128)
 print('bilinear bwd 128: hip-vs-cpu32 %.2e  hip-vs-f64 %.2e  cpu32-vs-f64 %.2e' % (float((gx_hip.cpu() - gx_cpu).abs().max()), float((gx_hip.cpu().double() - gx64).abs().max()), float((gx_cpu.double() - gx64).abs().max())))

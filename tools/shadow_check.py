@@ -14,7 +14,7 @@ from tartangan_amd import backend
 OUTS = {  # name -> indices of output tensor args
     'conv2d_fwd': [3], 'conv2d_dgrad': [2], 'conv2d_wgrad': [2, 3], 'channel_sum': [1], 'channel_bcast': [1], 'gemm': [2],
     'bn_train_stats': [1, 2], 'bn_act_fwd': [6], 'bn_act_bwd': [8, 9, 10], 'bn_act_dbwd': [10, 11, 12],
-    'up2x': [1], 'pool2': [1], 'bilinear_half_fwd': [1], 'bilinear_half_bwd': [1], 'maxpool2_fwd': [1], 'maxpool2_bwd': [2],
+    'up2x': [1], 'pool2': [1], 'bilinear_half_fwd': [1], 'bilinear_half_bwd': [2], 'maxpool2_fwd': [1], 'maxpool2_bwd': [2],
     'maxpool2_gather': [2], 'row_sum': [1], 'row_bcast': [1], 'add': [2], 'mul': [2], 'scale': [2], 'scale_dev': [3],
     'scale_add_dev': [3], 'dot': [3], 'lrelu_bwd': [3], 'tanh_fwd': [1], 'tanh_bwd': [2], 'softmax_fwd': [1],
     'softmax_bwd': [2], 'softmax_dbwd': [3], 'bce_logits': [2, 3], 'sumsq': [2], 'iqn_loss': [4, 5], 'sum_reps': [1], 'repeat_rows': [1],
