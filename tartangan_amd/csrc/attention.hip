@@ -2,87 +2,184 @@
 //     beta = softmax_m(theta^T phi)   (N x M, M = N/4)        o = g beta^T
 // without ever materialising beta (16 MiB per image at 128:3 in the generator).
 //
-// Head dims here are tiny (D = C/8 in {1..16}, DV = C/2 in {4..64}): the contraction is far too
-// thin for MFMA tiles, the work is exp/VALU-bound.  So: one lane per query
-// (forward, dtheta) or per key (dphi, dg), the other side's rows are staged in LDS and read as
-// wave-uniform broadcasts (every lane reads the same address: conflict-free), scores / softmax
-// weights / accumulators live in registers, online softmax over key tiles.
-//
 // Layouts are the reference's channel-major views: theta (B, D, N), phi (B, D, M), g (B, DV, M),
 // o (B, DV, N); lse (B, N) = log sum_m exp(score) is saved for the backward.
+//
+// Head dims are tiny (D = C/8 in {1..16}, DV = C/2 in {4..64}) but every contraction here is still a matrix product,
+// and v_mfma_f32_16x16x4_f32 has exactly the K = 4 that D = 4 needs.  One wave owns a 16-row tile of one side
+// (queries for forward / dtheta, keys for dphi / dg) and walks the other side in 16-row tiles; operands are loaded
+// straight from global memory (L2-resident: K and V of an image are a few KB) into the MFMA register layouts, scores
+// and probabilities never leave registers.  With lane l = (c = l & 15, g = l >> 4):
+//     A operand: A[row c][k g]        B operand: B[k g][col c]        result reg r: D[row 4g + r][col c]
+// A 16x16 result tile is reused as the B operand of the NEXT product without any data movement: result register r of
+// lane group g holds rows 4g + r, so taking "register r" as k-step r just enumerates the contraction index in the
+// order (r, g) -> row 4g + r, and the other operand is loaded in that same order (4 consecutive rows = one float4).
+// (An earlier one-lane-per-query VALU version spent 8x its issue time waiting on LDS broadcasts.)
 #include "common.h"
 
 namespace {
 
-constexpr int AT = 256;          // threads per workgroup = queries (or keys) per workgroup
-constexpr int KT = 64;           // rows of the other side staged per LDS tile
-constexpr int SUB = 16;          // scores handled per online-softmax rescale
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int D, int DV>
-__global__ void __launch_bounds__(AT) attn_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
-                                                      const float* __restrict__ g, float* __restrict__ o, float* __restrict__ lse,
-                                                      int N, int M) {
-  __shared__ float ph[KT][D];      // [key][d]   : one broadcast read fetches a key's whole phi row
-  __shared__ float gl[KT][DV];     // [key][dv]
-  const int b = blockIdx.y;
-  const int n = blockIdx.x * AT + threadIdx.x;
-  const bool live = n < N;
-  const float* th = theta + (int64_t)b * D * N;
-  float q[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) q[d] = live ? th[(int64_t)d * N + n] : 0.f;
-  float acc[DV];
-#pragma unroll
-  for (int v = 0; v < DV; ++v) acc[v] = 0.f;
-  float mx = -INFINITY, l = 0.f;
-  const float* pb = phi + (int64_t)b * D * M;
-  const float* gb = g + (int64_t)b * DV * M;
+constexpr int AT = 256;          // threads per workgroup: 4 waves, 16 tile rows each
 
-  for (int k0 = 0; k0 < M; k0 += KT) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < KT * D; e += AT) {
-      const int k = e % KT, d = e / KT;                     // coalesced along keys
-      ph[k][d] = (k0 + k < M) ? pb[(int64_t)d * M + k0 + k] : 0.f;
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0); }
+
+// Operand loads.  `full` (wave-uniform): every column this tile touches is in range and rows are 16-byte aligned, so
+// the loads are unconditional (rows past the head dim are clamped and zeroed by a select: no exec-mask branches in the
+// inner loops); otherwise every element is guarded.
+template <bool FULL>
+__device__ __forceinline__ float ld1(const float* __restrict__ p, int row, int rows, int64_t stride, int col, int cols) {
+  if (FULL) {
+    const float v = p[(int64_t)min(row, rows - 1) * stride + col];
+    return row < rows ? v : 0.f;
+  }
+  return (row < rows && col < cols) ? p[(int64_t)row * stride + col] : 0.f;
+}
+// 4 consecutive columns of one row (columns >= cols read as 0)
+template <bool FULL>
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int row, int rows, int64_t stride, int col, int cols) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (FULL) {
+    const float4 t = *reinterpret_cast<const float4*>(p + (int64_t)min(row, rows - 1) * stride + col);
+    if (row < rows) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    return v;
+  }
+  if (row < rows) {
+    const float* q = p + (int64_t)row * stride + col;
+    if (col < cols) v[0] = q[0];
+    if (col + 1 < cols) v[1] = q[1];
+    if (col + 2 < cols) v[2] = q[2];
+    if (col + 3 < cols) v[3] = q[3];
+  }
+  return v;
+}
+__device__ __forceinline__ float group_max(float v) {      // over the 4 lane groups (same c)
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+template <int D, int DV> struct AttnDims {
+  static constexpr int KS = (D + 3) / 4;       // k-steps of the score product
+  static constexpr int VT = (DV + 15) / 16;    // 16-row tiles of the value dimension
+  static constexpr int VS = (DV + 3) / 4;      // k-steps of a contraction over dv
+};
+constexpr int JT = 4;                          // 16-row tiles of the streamed side per loop iteration (forward, dtheta)
+constexpr int JK = 2;                          // ... for dphi / dg, whose per-tile operand set is larger
+
+// A wave owns RT 16-row tiles of its side (RT = 4 when that still leaves >= 4 waves per SIMD, else 1) and reuses every
+// streamed operand it loaded for all of them: with RT = 1 the 64x64-pixel attention map of the generator re-read K / V
+// (or Q / dO) from L2 once per 16 rows -- 1.4 GB per call -- and ran at a third of the matrix-core rate.
+
+// ---------------------------------------------------------------------------------------------------- forward
+// One step = 64 keys: per owned query tile 4 score tiles, ONE running-max update / accumulator rescale, 16 exp2 and the
+// PV products alternating between two accumulators (halves the dependent-MFMA chain).  Scores are kept in log2 units
+// (theta is scaled by log2 e on load) so that the softmax weights are bare v_exp_f32.
+template <int D, int DV, int RT, bool FULL>
+__device__ __forceinline__ void fwd_step(const float* __restrict__ pb, const float* __restrict__ gb, const float (&qB)[RT][(D + 3) / 4],
+                                         f32x4 (&acc)[RT][2][(DV + 15) / 16], float (&mx)[RT], float (&lpart)[RT], int k0, int M,
+                                         int c, int g) {
+  using A = AttnDims<D, DV>;
+  float kA[JT][A::KS];
+  f32x4 vA[JT][A::VT];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) kA[j][s] = ld1<FULL>(pb, 4 * s + g, D, M, k0 + 16 * j + c, M);
+#pragma unroll
+    for (int t = 0; t < A::VT; ++t) vA[j][t] = ld4<FULL>(gb, 16 * t + c, DV, M, k0 + 16 * j + 4 * g, M);
+  }
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    f32x4 st[JT];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      st[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < A::KS; ++s) st[j] = mfma16(kA[j][s], qB[q][s], st[j]);
     }
-    for (int e = threadIdx.x; e < KT * DV; e += AT) {
-      const int k = e % KT, v = e / KT;
-      gl[k][v] = (k0 + k < M) ? gb[(int64_t)v * M + k0 + k] : 0.f;
-    }
-    __syncthreads();
-    const int kn = min(KT, M - k0);
-    for (int ks = 0; ks < kn; ks += SUB) {
-      float s[SUB];
-      float tmax = -INFINITY;
 #pragma unroll
-      for (int u = 0; u < SUB; ++u) {
-        float sc = 0.f;
+    for (int j = 0; j < JT; ++j)
 #pragma unroll
-        for (int d = 0; d < D; ++d) sc = fmaf(q[d], ph[ks + u][d], sc);
-        sc = (ks + u < kn) ? sc : -INFINITY;
-        s[u] = sc;
-        tmax = fmaxf(tmax, sc);
+      for (int r = 0; r < 4; ++r) {
+        if (!FULL && k0 + 16 * j + 4 * g + r >= M) st[j][r] = -INFINITY;
+        tmax = fmaxf(tmax, st[j][r]);
       }
-      const float mnew = fmaxf(mx, tmax);
-      const float resc = __expf(mx - mnew);                 // exp(-inf) = 0 on the first tile
-      l *= resc;
+    const float mnew = fmaxf(mx[q], group_max(tmax));
+    const float resc = fast_exp2(mx[q] - mnew);             // 2^-inf = 0 on the first step
+    mx[q] = mnew;
+    float psum = 0.f;
 #pragma unroll
-      for (int v = 0; v < DV; ++v) acc[v] *= resc;
+    for (int j = 0; j < JT; ++j)
 #pragma unroll
-      for (int u = 0; u < SUB; ++u) {
-        const float p = __expf(s[u] - mnew);
-        l += p;
-#pragma unroll
-        for (int v = 0; v < DV; ++v) acc[v] = fmaf(p, gl[ks + u][v], acc[v]);
+      for (int r = 0; r < 4; ++r) {
+        st[j][r] = fast_exp2(st[j][r] - mnew);
+        psum += st[j][r];
       }
-      mx = mnew;
+    lpart[q] = lpart[q] * resc + psum;
+#pragma unroll
+    for (int t = 0; t < A::VT; ++t) {
+      acc[q][0][t] *= resc;
+      acc[q][1][t] *= resc;
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][j & 1][t] = mfma16(vA[j][t][r], st[j][r], acc[q][j & 1][t]);
     }
   }
-  if (live) {
-    const float inv = 1.f / l;
-    float* ob = o + (int64_t)b * DV * N;
+}
+
+template <int D, int DV, int RT>
+__global__ void __launch_bounds__(AT) attn_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                      const float* __restrict__ g_, float* __restrict__ o, float* __restrict__ lse,
+                                                      int N, int M, int vecM) {
+  using A = AttnDims<D, DV>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y;
+  const int q0 = (blockIdx.x * 4 + wave) * 16 * RT;
+  if (q0 >= N) return;                                      // whole wave; no barriers in this kernel
+  const float* th = theta + (int64_t)b * D * N;
+  const float* pb = phi + (int64_t)b * D * M;
+  const float* gb = g_ + (int64_t)b * DV * M;
+  float qB[RT][A::KS], mx[RT], lpart[RT];
+  f32x4 acc[RT][2][A::VT];
 #pragma unroll
-    for (int v = 0; v < DV; ++v) ob[(int64_t)v * N + n] = acc[v] * inv;
-    lse[(int64_t)b * N + n] = mx + __logf(l);
+  for (int q = 0; q < RT; ++q) {
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) qB[q][s] = ld1<false>(th, 4 * s + g, D, N, q0 + 16 * q + c, N) * LOG2E;
+#pragma unroll
+    for (int t = 0; t < A::VT; ++t) acc[q][0][t] = acc[q][1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mx[q] = -INFINITY;
+    lpart[q] = 0.f;
+  }
+  int k0 = 0;
+  if (vecM)
+    for (; k0 + 16 * JT <= M; k0 += 16 * JT) fwd_step<D, DV, RT, true>(pb, gb, qB, acc, mx, lpart, k0, M, c, g);
+  for (; k0 < M; k0 += 16 * JT) fwd_step<D, DV, RT, false>(pb, gb, qB, acc, mx, lpart, k0, M, c, g);
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    const float l = group_sum(lpart[q]);
+    const float inv = 1.f / l;
+    const int n = q0 + 16 * q + c;
+    if (n < N) {
+      float* ob = o + (int64_t)b * DV * N + n;
+#pragma unroll
+      for (int t = 0; t < A::VT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int dv = 16 * t + 4 * g + r;
+          if (dv < DV) ob[(int64_t)dv * N] = (acc[q][0][t][r] + acc[q][1][t][r]) * inv;
+        }
+      if (g == 0) lse[(int64_t)b * N + n] = (mx[q] + __log2f(l)) * LN2;
+    }
   }
 }
 
@@ -99,122 +196,182 @@ __global__ void __launch_bounds__(AT) attn_delta_kernel(const float* __restrict_
   delta[(int64_t)b * N + n] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------- dtheta
 // query-owned: dtheta[d][n] = sum_k ds(n,k) phi[d][k],  ds = p (dp - delta), p = exp(s - lse), dp = go_n . g_k
-template <int D, int DV>
-__global__ void __launch_bounds__(AT) attn_bwd_q_kernel(const float* __restrict__ go, const float* __restrict__ theta,
-                                                        const float* __restrict__ phi, const float* __restrict__ g,
-                                                        const float* __restrict__ lse, const float* __restrict__ delta,
-                                                        float* __restrict__ dtheta, int N, int M) {
-  __shared__ float ph[KT][D];
-  __shared__ float gl[KT][DV];
-  const int b = blockIdx.y;
-  const int n = blockIdx.x * AT + threadIdx.x;
-  const bool live = n < N;
-  const float* th = theta + (int64_t)b * D * N;
-  const float* gob = go + (int64_t)b * DV * N;
-  float q[D], dq[D], dout[DV];
+template <int D, int DV, int RT, bool FULL>
+__device__ __forceinline__ void bwd_q_step(const float* __restrict__ pb, const float* __restrict__ gb, const float (&qB)[RT][(D + 3) / 4],
+                                           const float (&doB)[RT][(DV + 3) / 4], const float (&L2)[RT], const float (&dl)[RT],
+                                           f32x4 (&dq)[RT][2], int k0, int M, int c, int g) {
+  using A = AttnDims<D, DV>;
+  float kA[JT][A::KS], vK[JT][A::VS];
+  f32x4 kT[JT];
 #pragma unroll
-  for (int d = 0; d < D; ++d) { q[d] = live ? th[(int64_t)d * N + n] : 0.f; dq[d] = 0.f; }
+  for (int j = 0; j < JT; ++j) {
 #pragma unroll
-  for (int v = 0; v < DV; ++v) dout[v] = live ? gob[(int64_t)v * N + n] : 0.f;
-  const float L = live ? lse[(int64_t)b * N + n] : 0.f;
-  const float dl = live ? delta[(int64_t)b * N + n] : 0.f;
-  const float* pb = phi + (int64_t)b * D * M;
-  const float* gb = g + (int64_t)b * DV * M;
-  for (int k0 = 0; k0 < M; k0 += KT) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < KT * D; e += AT) {
-      const int k = e % KT, d = e / KT;
-      ph[k][d] = (k0 + k < M) ? pb[(int64_t)d * M + k0 + k] : 0.f;
-    }
-    for (int e = threadIdx.x; e < KT * DV; e += AT) {
-      const int k = e % KT, v = e / KT;
-      gl[k][v] = (k0 + k < M) ? gb[(int64_t)v * M + k0 + k] : 0.f;
-    }
-    __syncthreads();
-    const int kn = min(KT, M - k0);
-    for (int k = 0; k < kn; ++k) {
-      float sc = 0.f, dp = 0.f;
+    for (int s = 0; s < A::KS; ++s) kA[j][s] = ld1<FULL>(pb, 4 * s + g, D, M, k0 + 16 * j + c, M);
 #pragma unroll
-      for (int d = 0; d < D; ++d) sc = fmaf(q[d], ph[k][d], sc);
-#pragma unroll
-      for (int v = 0; v < DV; ++v) dp = fmaf(dout[v], gl[k][v], dp);
-      const float ds = __expf(sc - L) * (dp - dl);
-#pragma unroll
-      for (int d = 0; d < D; ++d) dq[d] = fmaf(ds, ph[k][d], dq[d]);
-    }
+    for (int u = 0; u < A::VS; ++u) vK[j][u] = ld1<FULL>(gb, 4 * u + g, DV, M, k0 + 16 * j + c, M);  // V[key c][dv 4u+g]
+    kT[j] = ld4<FULL>(pb, c, D, M, k0 + 16 * j + 4 * g, M);                             // K^T[d c][keys k0+16j+4g+(0..3)]
   }
-  if (live) {
-    float* dt = dtheta + (int64_t)b * D * N;
 #pragma unroll
-    for (int d = 0; d < D; ++d) dt[(int64_t)d * N + n] = dq[d];
+  for (int q = 0; q < RT; ++q)
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < A::KS; ++s) st = mfma16(kA[j][s], qB[q][s], st);
+#pragma unroll
+      for (int u = 0; u < A::VS; ++u) dp = mfma16(vK[j][u], doB[q][u], dp);              // dP^T[key][query]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = (!FULL && k0 + 16 * j + 4 * g + r >= M) ? 0.f : fast_exp2(st[r] - L2[q]);
+        dq[q][j & 1] = mfma16(kT[j][r], p * (dp[r] - dl[q]), dq[q][j & 1]);             // dtheta^T[d 4g+r'][query c]
+      }
+    }
+}
+
+template <int D, int DV, int RT>
+__global__ void __launch_bounds__(AT) attn_bwd_q_kernel(const float* __restrict__ go, const float* __restrict__ theta,
+                                                        const float* __restrict__ phi, const float* __restrict__ g_,
+                                                        const float* __restrict__ lse, const float* __restrict__ delta,
+                                                        float* __restrict__ dtheta, int N, int M, int vecM) {
+  using A = AttnDims<D, DV>;
+  static_assert(D <= 16, "one 16-row tile of dtheta");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y;
+  const int q0 = (blockIdx.x * 4 + wave) * 16 * RT;
+  if (q0 >= N) return;
+  const float* th = theta + (int64_t)b * D * N;
+  const float* pb = phi + (int64_t)b * D * M;
+  const float* gb = g_ + (int64_t)b * DV * M;
+  const float* gob = go + (int64_t)b * DV * N;
+  float qB[RT][A::KS], doB[RT][A::VS], L2[RT], dl[RT];
+  f32x4 dq[RT][2];
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    const int n = q0 + 16 * q + c;
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) qB[q][s] = ld1<false>(th, 4 * s + g, D, N, n, N) * LOG2E;
+#pragma unroll
+    for (int u = 0; u < A::VS; ++u) doB[q][u] = ld1<false>(gob, 4 * u + g, DV, N, n, N);      // dO^T[dv 4u+g][query c]
+    L2[q] = n < N ? lse[(int64_t)b * N + n] * LOG2E : INFINITY;                               // dead query: p = 0
+    dl[q] = n < N ? delta[(int64_t)b * N + n] : 0.f;
+    dq[q][0] = dq[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int k0 = 0;
+  if (vecM)
+    for (; k0 + 16 * JT <= M; k0 += 16 * JT) bwd_q_step<D, DV, RT, true>(pb, gb, qB, doB, L2, dl, dq, k0, M, c, g);
+  for (; k0 < M; k0 += 16 * JT) bwd_q_step<D, DV, RT, false>(pb, gb, qB, doB, L2, dl, dq, k0, M, c, g);
+#pragma unroll
+  for (int q = 0; q < RT; ++q) {
+    const int n = q0 + 16 * q + c;
+    if (n < N) {
+      float* dt = dtheta + (int64_t)b * D * N + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * g + r < D) dt[(int64_t)(4 * g + r) * N] = dq[q][0][r] + dq[q][1][r];
+    }
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- dphi, dg
 // key-owned: dphi[d][k] = sum_n ds(n,k) theta[d][n];  dg[v][k] = sum_n p(n,k) go[v][n]
-template <int D, int DV>
+template <int D, int DV, int RT, bool FULL>
+__device__ __forceinline__ void bwd_k_step(const float* __restrict__ th, const float* __restrict__ gob, const float* __restrict__ lb,
+                                           const float* __restrict__ db, const float (&kB)[RT][(D + 3) / 4],
+                                           const float (&vB)[RT][(DV + 3) / 4], f32x4 (&dk)[RT], f32x4 (&dv_)[RT][(DV + 15) / 16],
+                                           int n0, int N, int c, int g) {
+  using A = AttnDims<D, DV>;
+  float qA[JK][A::KS], goA[JK][A::VS];
+  f32x4 L4[JK], d4[JK], qT[JK], goT[JK][A::VT];
+#pragma unroll
+  for (int j = 0; j < JK; ++j) {
+    const int nj = n0 + 16 * j;
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) qA[j][s] = ld1<FULL>(th, 4 * s + g, D, N, nj + c, N);        // Q[query c][d 4s+g]
+#pragma unroll
+    for (int u = 0; u < A::VS; ++u) goA[j][u] = ld1<FULL>(gob, 4 * u + g, DV, N, nj + c, N);    // dO[query c][dv 4u+g]
+    L4[j] = ld4<FULL>(lb, 0, 1, 0, nj + 4 * g, N) * LOG2E;
+    d4[j] = ld4<FULL>(db, 0, 1, 0, nj + 4 * g, N);
+    qT[j] = ld4<FULL>(th, c, D, N, nj + 4 * g, N);                                      // Q^T[d c][queries nj+4g+(0..3)]
+#pragma unroll
+    for (int t = 0; t < A::VT; ++t) goT[j][t] = ld4<FULL>(gob, 16 * t + c, DV, N, nj + 4 * g, N);   // dO^T[dv 16t+c][queries]
+  }
+#pragma unroll
+  for (int k = 0; k < RT; ++k)
+#pragma unroll
+    for (int j = 0; j < JK; ++j) {
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < A::KS; ++s) sc = mfma16(qA[j][s], kB[k][s], sc);              // S[query][key c]   (log2 units)
+#pragma unroll
+      for (int u = 0; u < A::VS; ++u) dp = mfma16(goA[j][u], vB[k][u], dp);             // dP[query][key c]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = (!FULL && n0 + 16 * j + 4 * g + r >= N) ? 0.f : fast_exp2(sc[r] - L4[j][r]);
+        dk[k] = mfma16(qT[j][r], p * (dp[r] - d4[j][r]), dk[k]);                        // dphi^T[d 4g+r'][key c]
+#pragma unroll
+        for (int t = 0; t < A::VT; ++t) dv_[k][t] = mfma16(goT[j][t][r], p, dv_[k][t]); // dg^T[dv 16t+4g+r'][key c]
+      }
+    }
+}
+
+template <int D, int DV, int RT>
 __global__ void __launch_bounds__(AT) attn_bwd_k_kernel(const float* __restrict__ go, const float* __restrict__ theta,
-                                                        const float* __restrict__ phi, const float* __restrict__ g,
+                                                        const float* __restrict__ phi, const float* __restrict__ g_,
                                                         const float* __restrict__ lse, const float* __restrict__ delta,
                                                         float* __restrict__ dphi, float* __restrict__ dg, int N, int M, int QS,
-                                                        int B) {
+                                                        int B, int vecN) {
   // blockIdx.z = query slice: the slice's sums go to partial buffers [QS][B][D or DV][M] (QS > 1) that
   // attn_reduce_k_kernel adds in a fixed order; QS == 1 writes dphi / dg directly
-  __shared__ float tq[KT][D];
-  __shared__ float dq[KT][DV];
-  __shared__ float ls[KT];
-  __shared__ float de[KT];
+  using A = AttnDims<D, DV>;
+  static_assert(D <= 16, "one 16-row tile of dphi");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
   const int b = blockIdx.y;
-  const int k = blockIdx.x * AT + threadIdx.x;
-  const bool live = k < M;
-  const float* pb = phi + (int64_t)b * D * M;
-  const float* gb = g + (int64_t)b * DV * M;
-  float kp[D], kg[DV], dkp[D], dkg[DV];
-#pragma unroll
-  for (int d = 0; d < D; ++d) { kp[d] = live ? pb[(int64_t)d * M + k] : 0.f; dkp[d] = 0.f; }
-#pragma unroll
-  for (int v = 0; v < DV; ++v) { kg[v] = live ? gb[(int64_t)v * M + k] : 0.f; dkg[v] = 0.f; }
+  const int k0 = (blockIdx.x * 4 + wave) * 16 * RT;
+  if (k0 >= M) return;
   const float* th = theta + (int64_t)b * D * N;
+  const float* pb = phi + (int64_t)b * D * M;
+  const float* gb = g_ + (int64_t)b * DV * M;
   const float* gob = go + (int64_t)b * DV * N;
-  const int slice = blockIdx.z;
-  const int per = ((N + QS - 1) / QS + KT - 1) / KT * KT;
-  const int n_begin = slice * per, n_end = min(N, n_begin + per);
-  for (int n0 = n_begin; n0 < n_end; n0 += KT) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < KT * D; e += AT) {
-      const int q = e % KT, d = e / KT;
-      tq[q][d] = (n0 + q < N) ? th[(int64_t)d * N + n0 + q] : 0.f;
-    }
-    for (int e = threadIdx.x; e < KT * DV; e += AT) {
-      const int q = e % KT, v = e / KT;
-      dq[q][v] = (n0 + q < N) ? gob[(int64_t)v * N + n0 + q] : 0.f;
-    }
-    for (int e = threadIdx.x; e < KT; e += AT) {
-      ls[e] = (n0 + e < N) ? lse[(int64_t)b * N + n0 + e] : INFINITY;     // p = exp(s - inf) = 0 for padding queries
-      de[e] = (n0 + e < N) ? delta[(int64_t)b * N + n0 + e] : 0.f;
-    }
-    __syncthreads();
-    for (int q = 0; q < KT; ++q) {
-      float sc = 0.f, dp = 0.f;
+  const float* lb = lse + (int64_t)b * N;
+  const float* db = delta + (int64_t)b * N;
+  float kB[RT][A::KS], vB[RT][A::VS];
+  f32x4 dk[RT], dv_[RT][A::VT];
 #pragma unroll
-      for (int d = 0; d < D; ++d) sc = fmaf(tq[q][d], kp[d], sc);
+  for (int k = 0; k < RT; ++k) {
 #pragma unroll
-      for (int v = 0; v < DV; ++v) dp = fmaf(dq[q][v], kg[v], dp);
-      const float p = __expf(sc - ls[q]);
-      const float ds = p * (dp - de[q]);
+    for (int s = 0; s < A::KS; ++s) kB[k][s] = ld1<false>(pb, 4 * s + g, D, M, k0 + 16 * k + c, M) * LOG2E;   // K^T[d 4s+g][key c]
 #pragma unroll
-      for (int d = 0; d < D; ++d) dkp[d] = fmaf(ds, tq[q][d], dkp[d]);
+    for (int u = 0; u < A::VS; ++u) vB[k][u] = ld1<false>(gb, 4 * u + g, DV, M, k0 + 16 * k + c, M);          // V^T[dv 4u+g][key c]
+    dk[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int v = 0; v < DV; ++v) dkg[v] = fmaf(p, dq[q][v], dkg[v]);
-    }
+    for (int t = 0; t < A::VT; ++t) dv_[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  if (live) {
-    float* dp_ = dphi + ((int64_t)slice * B + b) * D * M;
-    float* dg_ = dg + ((int64_t)slice * B + b) * DV * M;
+  const int slice = blockIdx.z;
+  const int per = ((N + QS - 1) / QS + 16 * JK - 1) / (16 * JK) * (16 * JK);
+  const int n_begin = slice * per, n_end = min(N, n_begin + per);
+  int n0 = n_begin;
+  if (vecN)
+    for (; n0 + 16 * JK <= n_end; n0 += 16 * JK) bwd_k_step<D, DV, RT, true>(th, gob, lb, db, kB, vB, dk, dv_, n0, N, c, g);
+  for (; n0 < n_end; n0 += 16 * JK) bwd_k_step<D, DV, RT, false>(th, gob, lb, db, kB, vB, dk, dv_, n0, N, c, g);
 #pragma unroll
-    for (int d = 0; d < D; ++d) dp_[(int64_t)d * M + k] = dkp[d];
+  for (int k = 0; k < RT; ++k) {
+    const int key = k0 + 16 * k + c;
+    if (key < M) {
+      float* dp_ = dphi + ((int64_t)slice * B + b) * D * M + key;
+      float* dg_ = dg + ((int64_t)slice * B + b) * DV * M + key;
 #pragma unroll
-    for (int v = 0; v < DV; ++v) dg_[(int64_t)v * M + k] = dkg[v];
+      for (int r = 0; r < 4; ++r)
+        if (4 * g + r < D) dp_[(int64_t)(4 * g + r) * M] = dk[k][r];
+#pragma unroll
+      for (int t = 0; t < A::VT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * t + 4 * g + r < DV) dg_[(int64_t)(16 * t + 4 * g + r) * M] = dv_[k][t][r];
+    }
   }
 }
 
@@ -227,21 +384,32 @@ __global__ void __launch_bounds__(AT) attn_reduce_k_kernel(const float* __restri
   }
 }
 
-// query slices for the key-owned kernel: enough workgroups to fill the chip
+// rows per wave (16 * RT) on the owning side: 4 tiles when that still gives every SIMD ~4 waves
+static inline int attn_rt(int B, int rows) { return ((int64_t)B * ((rows + 63) / 64) >= 4096) ? 4 : 1; }
+// query slices for the key-owned kernel: enough waves to fill the chip
 static inline int attn_qsplit(int B, int N, int M) {
-  const int64_t base = (int64_t)((M + AT - 1) / AT) * B;
-  int qs = (int)((1024 + base - 1) / base);
-  const int maxqs = (N + KT - 1) / KT;
+  const int64_t base1 = (int64_t)((M + 15) / 16) * B, base4 = (int64_t)((M + 63) / 64) * B;   // waves at QS = 1 for RT = 1 / 4
+  const int64_t base = base4 >= 1024 ? base4 : base1;
+  int qs = (int)((4096 + base - 1) / base);
+  const int maxqs = (N + 16 * JK - 1) / (16 * JK);
   if (qs > maxqs) qs = maxqs;
   if (qs > 16) qs = 16;
   if (qs < 1) qs = 1;
   return qs;
 }
+static inline int attn_rt_keys(int B, int M) { return ((int64_t)((M + 63) / 64) * B >= 1024) ? 4 : 1; }
+static inline int vec_rows(const void* p, int cols) { return (cols % 4 == 0) && tg_aligned16(p); }
 
 template <int D, int DV>
 int launch_fwd(const float* theta, const float* phi, const float* g, float* o, float* lse, int B, int N, int M, hipStream_t st) {
-  dim3 grid((N + AT - 1) / AT, B);
-  attn_fwd_kernel<D, DV><<<grid, AT, 0, st>>>(theta, phi, g, o, lse, N, M);
+  const int vm = vec_rows(g, M) && vec_rows(phi, M);
+  if (attn_rt(B, N) == 4) {
+    dim3 grid((N + 255) / 256, B);
+    attn_fwd_kernel<D, DV, 4><<<grid, AT, 0, st>>>(theta, phi, g, o, lse, N, M, vm);
+  } else {
+    dim3 grid((N + 63) / 64, B);
+    attn_fwd_kernel<D, DV, 1><<<grid, AT, 0, st>>>(theta, phi, g, o, lse, N, M, vm);
+  }
   return tg_launch_status();
 }
 template <int D, int DV>
@@ -249,15 +417,29 @@ int launch_bwd(const float* go, const float* theta, const float* phi, const floa
                float* dtheta, float* dphi, float* dg, float* ws, int B, int N, int M, hipStream_t st) {
   const int QS = attn_qsplit(B, N, M);
   float* delta = ws;
-  float* pphi = ws + (int64_t)B * N;
+  float* pphi = ws + (((int64_t)B * N + 3) / 4) * 4;
   float* pg = pphi + (int64_t)QS * B * D * M;
-  dim3 gq((N + AT - 1) / AT, B), gk((M + AT - 1) / AT, B, QS);
-  attn_delta_kernel<<<gq, AT, 0, st>>>(go, o, delta, DV, N);
-  attn_bwd_q_kernel<D, DV><<<gq, AT, 0, st>>>(go, theta, phi, g, lse, delta, dtheta, N, M);
-  if (QS == 1) {
-    attn_bwd_k_kernel<D, DV><<<gk, AT, 0, st>>>(go, theta, phi, g, lse, delta, dphi, dg, N, M, 1, B);
+  dim3 gd((N + AT - 1) / AT, B);
+  const int vecM = vec_rows(g, M) && vec_rows(phi, M);
+  const int vecN = vec_rows(theta, N) && vec_rows(go, N) && vec_rows(lse, N) && vec_rows(delta, N);
+  attn_delta_kernel<<<gd, AT, 0, st>>>(go, o, delta, DV, N);
+  if (attn_rt(B, N) == 4) {
+    dim3 gq((N + 255) / 256, B);
+    attn_bwd_q_kernel<D, DV, 4><<<gq, AT, 0, st>>>(go, theta, phi, g, lse, delta, dtheta, N, M, vecM);
   } else {
-    attn_bwd_k_kernel<D, DV><<<gk, AT, 0, st>>>(go, theta, phi, g, lse, delta, pphi, pg, N, M, QS, B);
+    dim3 gq((N + 63) / 64, B);
+    attn_bwd_q_kernel<D, DV, 1><<<gq, AT, 0, st>>>(go, theta, phi, g, lse, delta, dtheta, N, M, vecM);
+  }
+  float* ophi = QS == 1 ? dphi : pphi;
+  float* og = QS == 1 ? dg : pg;
+  if (attn_rt_keys(B, M) == 4) {
+    dim3 gk((M + 255) / 256, B, QS);
+    attn_bwd_k_kernel<D, DV, 4><<<gk, AT, 0, st>>>(go, theta, phi, g, lse, delta, ophi, og, N, M, QS, B, vecN);
+  } else {
+    dim3 gk((M + 63) / 64, B, QS);
+    attn_bwd_k_kernel<D, DV, 1><<<gk, AT, 0, st>>>(go, theta, phi, g, lse, delta, ophi, og, N, M, QS, B, vecN);
+  }
+  if (QS > 1) {
     const int64_t n1 = (int64_t)B * D * M, n2 = (int64_t)B * DV * M;
     attn_reduce_k_kernel<<<tg_ew_grid(n1, AT), AT, 0, st>>>(pphi, dphi, n1, QS);
     attn_reduce_k_kernel<<<tg_ew_grid(n2, AT), AT, 0, st>>>(pg, dg, n2, QS);
@@ -284,7 +466,7 @@ int tg_attn_supported(int D, int DV) {
 size_t tg_attn_bwd_workspace(int B, int D, int DV, int N, int M) {
   if (B <= 0 || D <= 0 || DV <= 0 || N <= 0 || M <= 0) return 0;
   const int QS = attn_qsplit(B, N, M);
-  return ((size_t)B * N + (size_t)QS * B * (D + DV) * M) * sizeof(float);
+  return ((((size_t)B * N + 3) / 4) * 4 + (size_t)QS * B * (D + DV) * M) * sizeof(float);
 }
 
 int tg_attn_fwd(const float* theta, const float* phi, const float* g, float* o, float* lse, int B, int D, int DV, int N, int M,

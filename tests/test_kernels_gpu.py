@@ -284,7 +284,9 @@ def test_softmax(K, shape):
 
 
 @pytest.mark.parametrize('dims', [(3, 4, 16, 1024, 256), (2, 16, 64, 256, 64), (2, 16, 64, 64, 16), (2, 1, 4, 1024, 256),
-                                  (1, 4, 16, 4096, 1024), (2, 8, 32, 300, 75), (1, 2, 8, 64, 16)])
+                                  (1, 4, 16, 4096, 1024), (2, 8, 32, 300, 75), (1, 2, 8, 64, 16),
+                                  # batches large enough for the 4-tiles-per-wave variants (aligned and ragged)
+                                  (256, 4, 16, 1024, 256), (256, 4, 16, 1000, 250), (128, 8, 32, 2048, 512), (260, 1, 4, 1020, 255)])
 def test_fused_attention(K, dims):
     B, D, DV, N, M = dims
     assert K.attn_supported(D, DV)
