@@ -118,18 +118,41 @@ class KernelTimer:
         for name, args, a, b in self.records:
             ms = max(a.elapsed_time(b) - base, 0.0)
             flops = 0.0
+            nbytes = 0.0
             if name in CONV_DIMS:
                 B, Cin, Cout, H, W, ks = args[CONV_DIMS[name]]
                 flops = 2.0 * B * Cin * Cout * H * W * ks * ks
-            d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0))
+                # every operand once: input, output (or the two activations of wgrad) and the filter
+                nbytes = 4.0 * (B * Cin * H * W + B * Cout * H * W + Cin * Cout * ks * ks)
+                if name == 'conv2d_fwd' and args[3] is not None:
+                    nbytes += 4.0 * B * Cout * H * W          # fused residual read
+            d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             d['ms'] += ms
             d['launches'] += 1
             d['flops'] += flops
+            d['bytes'] += nbytes
         return agg
 
 
 # where (B, Cin, Cout, H, W, ks) sit in each conv entry point's argument list (include/tartangan_amd.h)
 CONV_DIMS = {'conv2d_fwd': slice(5, 11), 'conv2d_dgrad': slice(3, 9), 'conv2d_wgrad': slice(6, 12)}
+
+
+def hbm_traffic_per_launch(a, agg):
+    """HBM bytes per conv fwd/dgrad launch from the committed PMC summary (profiles/r01_hbm_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, tools/pmc_traffic.sh, corrected as the MI355X guide
+    prescribes).  Counters cannot be collected from inside the timed process, so the number is only reported for the
+    workload it was measured on; otherwise null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic.json')
+    if not (os.path.exists(path) and a.config == '128:3' and a.trainer == 'cnn' and a.batch == 64):
+        return None
+    with open(path) as f:
+        k = json.load(f)['kernels']
+    f_, d_ = k.get('conv_fwd_kernel (fwd)'), k.get('conv_fwd_kernel (dgrad)')
+    if not f_ or not d_:
+        return None
+    nf, nd = agg['conv2d_fwd']['launches'], agg['conv2d_dgrad']['launches']
+    return round((nf * f_['hbm_bytes_per_launch'] + nd * d_['hbm_bytes_per_launch']) / (nf + nd))
 
 
 def cpu_baseline(config, kind, batch):
@@ -235,13 +258,13 @@ def main():
             agg = kt.summary() if world == 1 else {}
             tr._graphs, tr._graph_requested, tr.rng_feed.mode = saved
             if agg:
-                conv = {'ms': agg['conv2d_fwd']['ms'] + agg['conv2d_dgrad']['ms'],
-                        'launches': agg['conv2d_fwd']['launches'] + agg['conv2d_dgrad']['launches'],
-                        'flops': agg['conv2d_fwd']['flops'] + agg['conv2d_dgrad']['flops']}
+                conv = {k: agg['conv2d_fwd'][k] + agg['conv2d_dgrad'][k] for k in ('ms', 'launches', 'flops', 'bytes')}
                 ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
                 out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (MFMA implicit-GEMM conv, fwd + dgrad launches)',
                                    'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                   'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': None,
+                                   'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                                   'traffic': hbm_traffic_per_launch(a, agg),
+                                   'algorithmic_bytes_per_launch': round(conv['bytes'] / conv['launches']),
                                    'launches_per_step': conv['launches'],
                                    'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
                                    'algorithmic_flop_per_step': conv['flops']}

@@ -1,0 +1,38 @@
+"""Summarise tools/pmc_traffic.sh: per kernel family, HBM bytes per launch from FETCH_SIZE / WRITE_SIZE.
+
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950 FETCH_SIZE
+tallies the 128-byte requests of wide (16 B / lane) streaming reads at 64 bytes, i.e. reports half the bytes -> x2.
+WRITE_SIZE is exact for 16 B / lane streaming stores; the conv epilogue stores 4 B / lane (uncalibrated width, taken as is).
+"""
+import csv, glob, json, re, sys, collections
+
+def load(d, counter):
+    f = glob.glob(f'{d}/**/*counter_collection.csv', recursive=True)
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for p in f:
+        for r in csv.DictReader(open(p)):
+            if r['Counter_Name'] != counter:
+                continue
+            n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+            n = re.sub(r'^void ', '', n).split('(')[0]
+            fam = re.sub(r'<.*', '', n)
+            if fam == 'conv_fwd_kernel':
+                fam += ' (dgrad)' if re.search(r', true>$', n) else ' (fwd)'
+            agg[fam][0] += 1
+            agg[fam][1] += float(r['Counter_Value'])
+    return agg
+
+root = sys.argv[1]
+fetch, write = load(f'{root}/fetch', 'FETCH_SIZE'), load(f'{root}/write', 'WRITE_SIZE')
+out = {}
+for fam in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 0])[1] + write.get(k, [0, 0])[1])):
+    nf, sf = fetch.get(fam, [0, 0.0]); nw, sw = write.get(fam, [0, 0.0])
+    if not nf or not nw:
+        continue
+    rd = 2.0 * sf * 1024 / nf          # gfx950 correction
+    wr = sw * 1024 / nw
+    out[fam] = {'launches_sampled': nf, 'fetch_bytes_per_launch': round(rd), 'write_bytes_per_launch': round(wr),
+                'hbm_bytes_per_launch': round(rd + wr)}
+print(json.dumps({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 2 --warmup 1',
+                  'corrections': 'KiB -> bytes; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B)',
+                  'kernels': dict(list(out.items())[:40])}, indent=1))
