@@ -77,20 +77,23 @@ __global__ void __launch_bounds__(GT) gemm_kernel(const float* __restrict__ A, c
 }
 
 // Skinny product C (M x N) = A (M x K) B (K x N), M <= 16, both row-major, K long: the attention backward's
-// dphi = theta ds / dg = go beta under double backward (M = 4 / 16, K = 1024, N = 256 at 128:3).  The 64x64 tile
-// kernel above would use 4/64 of its rows; here a workgroup owns 64 columns, its 4 waves split K, every B element
-// is read once (coalesced along N) and A is broadcast from LDS.
-constexpr int SK_KC = 256;      // K chunk staged per iteration
+// dphi = theta ds / dg = go beta under double backward (M = 4 / 16, K = 1024, N = 256 at 128:3).  Pure streaming of B
+// (64 MiB per call at batch 64): a workgroup owns 16 columns, its 256 threads are 16 columns x 16 K-slices, so a
+// wave-load covers 4 rows x 64 contiguous bytes and the grid is N/16 x batch workgroups (enough loads in flight to
+// stream at HBM rate; the first version, 64 columns per workgroup, had one workgroup per CU and ran at 0.8 TB/s).
+// A is broadcast from LDS; the 16 K-slices are combined through LDS in a fixed order.
+constexpr int SK_KC = 512;      // K chunk of A staged per iteration
+constexpr int SK_COLS = 16, SK_SL = GT / SK_COLS;
 template <int MM>
 __global__ void __launch_bounds__(GT) gemm_skinny_nn_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
                                                             const float* __restrict__ bias, int M, int N, int K, int lda, int ldb, int ldc,
                                                             int64_t sA, int64_t sB, int64_t sC, float beta) {
   __shared__ float As[MM][SK_KC + 1];
-  __shared__ float red[4][MM][64];
+  __shared__ float red[SK_SL][MM][SK_COLS];
   const int batch = blockIdx.y;
   A += batch * sA; Bm += batch * sB; C += batch * sC;
-  const int col = threadIdx.x & 63, ks = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + col;
+  const int col = threadIdx.x % SK_COLS, ks = threadIdx.x / SK_COLS;
+  const int n = blockIdx.x * SK_COLS + col;
   float acc[MM];
 #pragma unroll
   for (int m = 0; m < MM; ++m) acc[m] = 0.f;
@@ -102,7 +105,8 @@ __global__ void __launch_bounds__(GT) gemm_skinny_nn_kernel(const float* __restr
     }
     __syncthreads();
     const int kend = min(SK_KC, K - k0);
-    for (int k = ks; k < kend; k += 4) {
+#pragma unroll 4
+    for (int k = ks; k < kend; k += SK_SL) {
       const float b = (n < N) ? Bm[(int64_t)(k0 + k) * ldb + n] : 0.f;
 #pragma unroll
       for (int m = 0; m < MM; ++m) acc[m] = fmaf(As[m][k], b, acc[m]);
@@ -111,13 +115,62 @@ __global__ void __launch_bounds__(GT) gemm_skinny_nn_kernel(const float* __restr
 #pragma unroll
   for (int m = 0; m < MM; ++m) red[ks][m][col] = acc[m];
   __syncthreads();
-  for (int e = threadIdx.x; e < MM * 64; e += GT) {
-    const int m = e >> 6, c = e & 63;
-    const int gn = blockIdx.x * 64 + c;
+  for (int e = threadIdx.x; e < MM * SK_COLS; e += GT) {
+    const int m = e / SK_COLS, c = e % SK_COLS;
+    const int gn = blockIdx.x * SK_COLS + c;
     if (m < M && gn < N) {
-      float r = (red[0][m][c] + red[1][m][c]) + (red[2][m][c] + red[3][m][c]) + (bias ? bias[gn] : 0.f);
+      float r = 0.f;
+#pragma unroll
+      for (int q = 0; q < SK_SL; ++q) r += red[q][m][c];
+      r += bias ? bias[gn] : 0.f;
       if (beta != 0.f) r += beta * C[(int64_t)m * ldc + gn];
       C[(int64_t)m * ldc + gn] = r;
+    }
+  }
+}
+
+// Skinny product with B transposed: C (M x N) = A (M x K) B^T, B stored (N x K) row-major, M <= 16 -- the composed
+// attention's o = g beta^T and dtheta = phi ds^T (M = 16 / 4, N = 1024, K = 256): again one pass over B.  On the matrix
+// cores, transposed: C^T tile (16 rows of B) x (16 = padded M).  Lane (c, g) loads B[n0 + c][16 s + 4 g + (0..3)] as one
+// float4 (a wave-load = 16 rows x 64 contiguous bytes) and uses component j as the A operand of k-step (s, j); the k
+// index of that step is 16 s + 4 g + j, and A^T is loaded in the same order.
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(GT) gemm_skinny_nt_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
+                                                            const float* __restrict__ bias, int M, int N, int K, int lda, int ldb, int ldc,
+                                                            int64_t sA, int64_t sB, int64_t sC, float beta) {
+  const int batch = blockIdx.y;
+  A += batch * sA; Bm += batch * sB; C += batch * sC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * 16;
+  if (n0 >= N) return;                                   // whole wave; no barriers
+  const int brow = min(n0 + c, N - 1), arow = min(c, M - 1);
+  const float* bp = Bm + (int64_t)brow * ldb + 4 * g;
+  const float* ap = A + (int64_t)arow * lda + 4 * g;
+  f32x4_ acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 32) {                    // host guarantees K % 32 == 0 and 16-byte aligned rows
+    const float4 b0 = *reinterpret_cast<const float4*>(bp + k0), b1 = *reinterpret_cast<const float4*>(bp + k0 + 16);
+    float4 a0 = *reinterpret_cast<const float4*>(ap + k0), a1 = *reinterpret_cast<const float4*>(ap + k0 + 16);
+    if (c >= M) { a0 = make_float4(0.f, 0.f, 0.f, 0.f); a1 = a0; }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0.x, a0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1.x, a1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0.y, a0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1.y, a1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0.z, a0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1.z, a1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0.w, a0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1.w, a1.w, acc1, 0, 0, 0);
+  }
+  // result register r of lane (c, g): C^T[n0 + 4g + r][m = c]
+  if (c < M) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gn = n0 + 4 * g + r;
+      if (gn < N) {
+        float v = acc0[r] + acc1[r] + (bias ? bias[gn] : 0.f);
+        if (beta != 0.f) v += beta * C[(int64_t)c * ldc + gn];
+        C[(int64_t)c * ldc + gn] = v;
+      }
     }
   }
 }
@@ -132,8 +185,14 @@ extern "C" int tg_gemm(const float* A, const float* Bm, float* C, const float* b
   if (lda < (transA ? M : K) || ldb < (transB ? K : N) || ldc < N) return TG_EINVAL;
   if (batch > 65535) return TG_EUNSUPPORTED;
   hipStream_t st = tg_stream(stream);
+  if (!transA && transB && M <= 16 && K % 32 == 0 && N >= 64 && lda % 4 == 0 && ldb % 4 == 0 && strideA % 4 == 0 && strideB % 4 == 0 &&
+      tg_aligned16(A) && tg_aligned16(Bm)) {
+    dim3 tgrid((N + 63) / 64, batch);
+    gemm_skinny_nt_kernel<<<tgrid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
+    return tg_launch_status();
+  }
   if (!transA && !transB && M <= 16 && K >= 256) {
-    dim3 sgrid((N + 63) / 64, batch);
+    dim3 sgrid((N + SK_COLS - 1) / SK_COLS, batch);
     if (M <= 4) gemm_skinny_nn_kernel<4><<<sgrid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
     else gemm_skinny_nn_kernel<16><<<sgrid, GT, 0, st>>>(A, Bm, C, bias_n, M, N, K, lda, ldb, ldc, strideA, strideB, strideC, beta);
     return tg_launch_status();

@@ -210,6 +210,8 @@ GEMM_CASES = [
     (64, 2048, 256, 0, 1, 1), (64, 1, 128, 0, 1, 1), (512, 128, 20, 0, 1, 1), (256, 64, 16, 1, 0, 3),
     (16, 256, 64, 0, 1, 3), (4096, 1024, 4, 1, 0, 2), (100, 37, 19, 1, 1, 2), (33, 65, 17, 0, 0, 1),
     (4, 256, 1024, 0, 0, 3), (16, 256, 1024, 0, 0, 2), (3, 70, 300, 0, 0, 2), (9, 130, 513, 0, 0, 1),
+    # skinny, B transposed (matrix-core path): aligned, ragged N, M not a multiple of 4
+    (16, 1024, 256, 0, 1, 3), (4, 1024, 256, 0, 1, 2), (5, 100, 64, 0, 1, 2), (1, 77, 32, 0, 1, 1), (13, 4096, 96, 0, 1, 1),
 ]
 
 
