@@ -58,6 +58,8 @@ CONV_SHAPES = [
     # many pixel tiles with a short reduction, ragged and aligned
     (8, 16, 16, 128, 128, 3), (3, 5, 7, 250, 200, 3), (2, 32, 32, 256, 256, 3), (9, 20, 40, 96, 128, 3), (5, 24, 12, 130, 127, 3),
     (8, 3, 16, 128, 128, 1), (8, 16, 3, 128, 128, 1), (4, 100, 33, 192, 128, 1), (33, 32, 16, 64, 64, 1),
+    # direct few-channel 1x1 kernel: every accumulator width, vector and scalar pixel paths, both filter orientations
+    (3, 32, 4, 32, 32, 1), (2, 5, 7, 9, 11, 1), (2, 64, 8, 16, 16, 1), (2, 128, 6, 20, 20, 1), (3, 200, 3, 8, 8, 1), (2, 8, 84, 8, 8, 1),
 ]
 
 
