@@ -88,8 +88,9 @@ template <int MM>
 __global__ void __launch_bounds__(GT) gemm_skinny_nn_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C,
                                                             const float* __restrict__ bias, int M, int N, int K, int lda, int ldb, int ldc,
                                                             int64_t sA, int64_t sB, int64_t sC, float beta) {
-  __shared__ float As[MM][SK_KC + 1];
+  __shared__ __attribute__((aligned(16))) float As[SK_KC][MM];        // [k][m]: the MM values of one k are read as float4 broadcasts
   __shared__ float red[SK_SL][MM][SK_COLS];
+  static_assert(MM % 4 == 0, "A rows are read four at a time");
   const int batch = blockIdx.y;
   A += batch * sA; Bm += batch * sB; C += batch * sC;
   const int col = threadIdx.x % SK_COLS, ks = threadIdx.x / SK_COLS;
@@ -100,8 +101,8 @@ __global__ void __launch_bounds__(GT) gemm_skinny_nn_kernel(const float* __restr
   for (int k0 = 0; k0 < K; k0 += SK_KC) {
     __syncthreads();
     for (int e = threadIdx.x; e < MM * SK_KC; e += GT) {
-      const int m = e / SK_KC, k = e - m * SK_KC;
-      As[m][k] = (m < M && k0 + k < K) ? A[(int64_t)m * lda + k0 + k] : 0.f;
+      const int m = e / SK_KC, k = e - m * SK_KC;                     // coalesced along k
+      As[k][m] = (m < M && k0 + k < K) ? A[(int64_t)m * lda + k0 + k] : 0.f;
     }
     __syncthreads();
     const int kend = min(SK_KC, K - k0);
@@ -109,7 +110,13 @@ __global__ void __launch_bounds__(GT) gemm_skinny_nn_kernel(const float* __restr
     for (int k = ks; k < kend; k += SK_SL) {
       const float b = (n < N) ? Bm[(int64_t)(k0 + k) * ldb + n] : 0.f;
 #pragma unroll
-      for (int m = 0; m < MM; ++m) acc[m] = fmaf(As[m][k], b, acc[m]);
+      for (int m4 = 0; m4 < MM / 4; ++m4) {
+        const float4 a = *reinterpret_cast<const float4*>(&As[k][4 * m4]);
+        acc[4 * m4] = fmaf(a.x, b, acc[4 * m4]);
+        acc[4 * m4 + 1] = fmaf(a.y, b, acc[4 * m4 + 1]);
+        acc[4 * m4 + 2] = fmaf(a.z, b, acc[4 * m4 + 2]);
+        acc[4 * m4 + 3] = fmaf(a.w, b, acc[4 * m4 + 3]);
+      }
     }
   }
 #pragma unroll
