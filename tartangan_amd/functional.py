@@ -47,6 +47,32 @@ def _grad_sink(p):
     return g
 
 
+class _InputGradsOnly:
+    active = False
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    """Tell the layer Functions that the enclosing ``torch.autograd.grad`` call asks for gradients of DATA only.
+
+    A custom Function cannot see which of its inputs a particular backward call actually needs
+    (``ctx.needs_input_grad`` is fixed at forward time), so without this hint the R1 penalty's first-order pass
+    (``autograd.grad(outputs=d_real.sum(), inputs=real)``, reference models/losses.py:23-26) would also compute --
+    and throw away -- every weight and bias gradient of the discriminator: a fifth of all weight-gradient work
+    of a training step.  Used by ``models.losses.gradient_penalty`` only.
+    """
+    prev = _InputGradsOnly.active
+    _InputGradsOnly.active = True
+    try:
+        yield
+    finally:
+        _InputGradsOnly.active = prev
+
+
+def _param_grads_wanted():
+    return not _InputGradsOnly.active
+
+
 # =========================================================================== conv
 class _ConvFwd(Function):
     """y = conv(x, w) + bias [+ residual]; the residual add of the reference's blocks (x + h) rides in the epilogue."""
@@ -69,8 +95,8 @@ class _ConvFwd(Function):
         x, w, bias = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gw = gb = None
-        need_w = ctx.needs_input_grad[1]
-        need_b = bias is not None and ctx.needs_input_grad[2]
+        need_w = ctx.needs_input_grad[1] and _param_grads_wanted()
+        need_b = bias is not None and ctx.needs_input_grad[2] and _param_grads_wanted()
         if ctx.needs_input_grad[0]:
             gx = _ConvDgrad.apply(gy, w)
         sink_w, sink_b = _grad_sink(w), _grad_sink(bias)
@@ -283,7 +309,7 @@ class _Linear(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = _Gemm.apply(gy, w, False, False)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _param_grads_wanted():
             sink = _grad_sink(w)
             if sink is not None:          # gw += gy^T x straight into the flat bucket
                 M, N = gy.shape
@@ -291,7 +317,7 @@ class _Linear(Function):
                 K().gemm(gy, x, sink, None, N, Kd, M, N, Kd, Kd, 1, 0, 1, 0, 0, 0, 1.0)
             else:
                 gw = _Gemm.apply(gy, x, True, False)
-        if bias is not None and ctx.needs_input_grad[2]:
+        if bias is not None and ctx.needs_input_grad[2] and _param_grads_wanted():
             sink = _grad_sink(bias)
             if sink is not None:
                 M, N = gy.shape
@@ -775,7 +801,7 @@ class _ScaleAddDev(Function):
     def backward(ctx, g):
         s, a = ctx.saved_tensors
         gs = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and (_param_grads_wanted() or not s.is_leaf):
             sink = _grad_sink(s)
             if sink is not None:
                 gc = g.contiguous()

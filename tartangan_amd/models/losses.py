@@ -22,7 +22,8 @@ def gradient_penalty(preds, data):
     """mean_b sum_chw (d sum(preds) / d data)^2, differentiable w.r.t. the D parameters."""
     batch_size = data.size(0)
     total = TF._RowSum.apply(preds, preds.dim(), 1.0)           # preds.sum()
-    grad_dout = torch.autograd.grad(
-        outputs=total, inputs=data, create_graph=True, retain_graph=True, only_inputs=True)[0]
+    with TF.input_grads_only():                                 # d/d(data) only: no parameter gradients in this pass
+        grad_dout = torch.autograd.grad(
+            outputs=total, inputs=data, create_graph=True, retain_graph=True, only_inputs=True)[0]
     assert grad_dout.size() == data.size()
     return TF.sumsq(grad_dout, 1.0 / batch_size)
