@@ -90,18 +90,21 @@ int tg_gemm(const float* A, const float* Bm, float* C, const float* bias_n /*nul
  * Workspace: tg_bn_workspace(B,C,HW) bytes.                                       */
 size_t tg_bn_workspace(int B, int C, int HW);
 /* batch mean / 1/sqrt(biased var + eps); optional running-stat update
- * (running_var uses the unbiased variance, momentum as nn.BatchNorm2d); *num_batches_tracked += 1 */
+ * (running_var uses the unbiased variance, momentum as nn.BatchNorm2d); *num_batches_tracked += 1.
+ * replicate >= 1: x stands for a tensor in which every element occurs `replicate` times (the generator normalises
+ * nearest-upsampled activations, generator.py:52-57: same mean and biased variance, so the statistics are taken at the
+ * low resolution; only the unbiased correction n/(n-1) of running_var needs the true count n = replicate*B*HW).     */
 int tg_bn_train_stats(const float* x, float* mean, float* invstd,
                       float* running_mean /*nullable*/, float* running_var /*nullable*/,
                       int64_t* num_batches_tracked /*nullable*/,
-                      float momentum, float eps, float* workspace, int B, int C, int HW, void* stream);
+                      float momentum, float eps, float* workspace, int B, int C, int HW, int replicate, void* stream);
 /* training forward in one call: tg_bn_train_stats followed by tg_bn_act_fwd (one kernel when a channel
  * has <= 16384 elements)                                                                              */
 int tg_bn_train_fwd(const float* x, float* mean, float* invstd,
                     float* running_mean /*nullable*/, float* running_var /*nullable*/,
                     int64_t* num_batches_tracked /*nullable*/, const float* gamma, const float* beta,
                     float slope, float momentum, float eps, float* z, float* workspace,
-                    int B, int C, int HW, void* stream);
+                    int B, int C, int HW, int replicate, void* stream);
 /* eval mode: mean = running_mean, invstd = 1/sqrt(running_var + eps) */
 int tg_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd,
                      float eps, int C, void* stream);

@@ -53,7 +53,7 @@ struct RedStats {
 
 __global__ void stats_stage2(const double* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
                              float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv,
-                             int64_t* __restrict__ nbt, float momentum, float eps, int B, int C, int HW, int S) {
+                             int64_t* __restrict__ nbt, float momentum, float eps, int B, int C, int HW, int S, int rep) {
   const int c = blockIdx.x;                       // one wave per channel
   const double n = (double)B * HW;
   const double pivot = (double)x[(int64_t)c * HW];
@@ -67,7 +67,8 @@ __global__ void stats_stage2(const double* __restrict__ partial, const float* __
   mean[c] = (float)m;
   invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
   if (rm != nullptr) {
-    const double unbiased = n > 1.0 ? var * (n / (n - 1.0)) : var;
+    const double nr = n * rep;                     // element count of the tensor these statistics stand for
+    const double unbiased = nr > 1.0 ? var * (nr / (nr - 1.0)) : var;
     rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * m);
     rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
   }
@@ -116,7 +117,7 @@ struct FwdStatsBody {
   int64_t* nbt;
   const float *gamma, *beta;
   float slope, momentum, eps;
-  int B, HW, S;
+  int B, HW, S, rep;
   float a, b;
   __device__ void begin(int c, bool lead) {
     const double n = (double)B * HW;
@@ -134,7 +135,8 @@ struct FwdStatsBody {
       mean[c] = mf;
       invstd[c] = rf;
       if (rm != nullptr) {
-        const double unbiased = n > 1.0 ? var * (n / (n - 1.0)) : var;
+        const double nr = n * rep;
+        const double unbiased = nr > 1.0 ? var * (nr / (nr - 1.0)) : var;
         rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * m);
         rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
       }
@@ -382,7 +384,7 @@ __device__ __forceinline__ double block_sum_d1024(double v, double* scratch) {
 __global__ void __launch_bounds__(SB) bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
-                                                          float momentum, float eps, float* __restrict__ z, int B, int C, int HW) {
+                                                          float momentum, float eps, float* __restrict__ z, int B, int C, int HW, int rep) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
   const SmallIdx ix(B, C, HW, c);
@@ -404,7 +406,8 @@ __global__ void __launch_bounds__(SB) bn_small_fwd_kernel(const float* __restric
     mean[c] = mf;
     invstd[c] = rf;
     if (rm != nullptr) {
-      const double unbiased = n > 1.0 ? var * (n / (n - 1.0)) : var;
+      const double nr = n * rep;
+      const double unbiased = nr > 1.0 ? var * (nr / (nr - 1.0)) : var;
       rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * m);
       rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
     }
@@ -513,29 +516,29 @@ size_t tg_bn_workspace(int B, int C, int HW) {
 
 int tg_bn_train_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
                       int64_t* num_batches_tracked, float momentum, float eps, float* workspace, int B, int C, int HW,
-                      void* stream) {
+                      int replicate, void* stream) {
   TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(workspace);
-  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW); TG_CHECK_POS(replicate);
   if ((running_mean == nullptr) != (running_var == nullptr)) return TG_EINVAL;
   hipStream_t st = tg_stream(stream);
   Parts p = split_ws(workspace, B, C, HW);
   RedStats red{x, C, HW, 0.f};
   planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x));
   stats_stage2<<<C, 64, 0, st>>>(p.partial, x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, B, C, HW,
-                                            planes::splits(B, C, HW));
+                                            planes::splits(B, C, HW), replicate);
   return tg_launch_status();
 }
 
 int tg_bn_train_fwd(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, const float* gamma, const float* beta, float slope, float momentum, float eps,
-                    float* z, float* workspace, int B, int C, int HW, void* stream) {
+                    float* z, float* workspace, int B, int C, int HW, int replicate, void* stream) {
   TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta); TG_CHECK_PTR(z);
   TG_CHECK_PTR(workspace);
-  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW); TG_CHECK_POS(replicate);
   if ((running_mean == nullptr) != (running_var == nullptr)) return TG_EINVAL;
   if (small_case(B, C, HW)) {
     bn_small_fwd_kernel<<<C, SB, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
-                                                            gamma, beta, slope, momentum, eps, z, B, C, HW);
+                                                            gamma, beta, slope, momentum, eps, z, B, C, HW, replicate);
     return tg_launch_status();
   }
   if (planes::big(HW) && tg_aligned16(x) && tg_aligned16(z)) {
@@ -545,12 +548,12 @@ int tg_bn_train_fwd(const float* x, float* mean, float* invstd, float* running_m
     RedStats red{x, C, HW, 0.f};
     planes::launch_reduce(red, p.partial, B, C, HW, st, true);
     FwdStatsBody body{x, z, p.partial, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta,
-                      slope, momentum, eps, B, HW, planes::splits(B, C, HW), 0.f, 0.f};
+                      slope, momentum, eps, B, HW, planes::splits(B, C, HW), replicate, 0.f, 0.f};
     planes::launch_map_begin(body, B, C, HW, st);
     return tg_launch_status();
   }
   if (int rc = tg_bn_train_stats(x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, workspace, B, C,
-                                 HW, stream))
+                                 HW, replicate, stream))
     return rc;
   return tg_bn_act_fwd(x, mean, invstd, gamma, beta, slope, z, B, C, HW, stream);
 }

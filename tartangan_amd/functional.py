@@ -334,7 +334,8 @@ def linear(x, weight, bias=None):
 # =========================================================================== BatchNorm (+LeakyReLU)
 class _BNAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, num_batches_tracked=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, num_batches_tracked=None,
+                replicate=1):
         x = x.contiguous()
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
@@ -343,7 +344,7 @@ class _BNAct(Function):
         if training:
             ws = _ws(x, K().bn_workspace(B, C, hw))
             K().bn_train_fwd(x, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta,
-                             float(slope), float(momentum), float(eps), z, ws, B, C, hw)
+                             float(slope), float(momentum), float(eps), z, ws, B, C, hw, int(replicate))
         else:
             K().bn_eval_stats(running_mean, running_var, mean, invstd, float(eps), C)
             K().bn_act_fwd(x, mean, invstd, gamma, beta, float(slope), z, B, C, hw)
@@ -364,10 +365,10 @@ class _BNAct(Function):
             ws = _ws(x, K().bn_workspace(B, C, hw))
             K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, ctx.slope, int(ctx.training), gx, sink_g, sink_b, ws,
                            B, C, hw, 1)
-            return gx, None, None, None, None, None, None, None, None, None
+            return gx, None, None, None, None, None, None, None, None, None, None
         gx, gg, gb = _BNActBwd.apply(gz, x, gamma, beta, mean, invstd, ctx.slope, ctx.training,
                                      ctx.needs_input_grad[0])
-        return gx, gg, gb, None, None, None, None, None, None, None
+        return gx, gg, gb, None, None, None, None, None, None, None, None
 
 
 class _BNActBwd(Function):
@@ -401,11 +402,12 @@ class _BNActBwd(Function):
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, slope=1.0,
-                   num_batches_tracked=None):
+                   num_batches_tracked=None, replicate=1):
     """BatchNorm2d followed by LeakyReLU(slope) in one pass (slope=1: plain BN).  In training mode the
-    stats kernel also bumps ``num_batches_tracked`` (int64 device scalar) when given."""
+    stats kernel also bumps ``num_batches_tracked`` (int64 device scalar) when given.  ``replicate``: ``x`` stands
+    for a tensor holding every element that many times (see tg_bn_train_stats); only running_var depends on it."""
     return _BNAct.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, slope,
-                        num_batches_tracked)
+                        num_batches_tracked, replicate)
 
 
 # =========================================================================== resampling

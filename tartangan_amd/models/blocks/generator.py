@@ -36,11 +36,23 @@ class ResidualGeneratorBlock(nn.Module):
         self.convs = nn.Sequential(*body)
 
     def forward(self, x):
-        xs = x
-        if self.upsample:
-            xs, x = TF.fork_upsample_nearest2x(x)        # one graph node for both uses (functional._ForkUp2x)
+        """reference generator.py:52-62: x = up(x); h = convs(x); return h + project(x)"""
+        if not self.upsample:
+            shortcut = x if self.project_input is None else run_layers(self.project_input, x)
+            return run_layers(self.convs, x, residual=shortcut)      # x + h, the add fused into the last conv
+        mods = list(self.convs)
+        low_res_norm = (len(mods) > 2 and isinstance(mods[0], BatchNorm2d) and isinstance(mods[1], LeakyReLU))
+        if low_res_norm and (self.project_input is None or all(type(m) is Conv2d for m in self.project_input)):
+            # Everything between the block input and the first 3x3 conv commutes with nearest-neighbour upsampling:
+            # BatchNorm statistics of an upsampled tensor are those of its source (each element 4 times), LeakyReLU is
+            # elementwise, and the 1x1 projection acts per pixel.  So norm + activation and the projection run at
+            # the LOW resolution (a quarter of the traffic / FLOPs) and only their results are upsampled.
+            a = mods[0].forward_act(x, mods[1].negative_slope, replicate=4)
+            shortcut = TF.upsample_nearest2x(x if self.project_input is None else run_layers(self.project_input, x))
+            return run_layers(self.convs[2:], TF.upsample_nearest2x(a), residual=shortcut)
+        xs, xu = TF.fork_upsample_nearest2x(x)           # one graph node for both uses (functional._ForkUp2x)
         shortcut = xs if self.project_input is None else run_layers(self.project_input, xs)
-        return run_layers(self.convs, x, residual=shortcut)          # x + h, the add fused into the last conv
+        return run_layers(self.convs, xu, residual=shortcut)
 
 
 class GeneratorInputMLP(nn.Module):

@@ -84,18 +84,20 @@ class BatchNorm2d(nn.BatchNorm2d):
     """Train-mode batch statistics or eval-mode running statistics; ``forward_act``
     fuses the LeakyReLU that follows it in every reference block."""
 
-    def _run(self, x, slope):
+    def _run(self, x, slope, replicate=1):
         if self.momentum is None or not self.affine or not self.track_running_stats:
             raise NotImplementedError('tartangan_amd.BatchNorm2d: default nn.BatchNorm2d options only')
         return TF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
                                  self.training, self.momentum, self.eps, slope,
-                                 self.num_batches_tracked if self.training else None)
+                                 self.num_batches_tracked if self.training else None, replicate)
 
     def forward(self, x):
         return self._run(x, 1.0)
 
-    def forward_act(self, x, slope):
-        return self._run(x, slope)
+    def forward_act(self, x, slope, replicate=1):
+        """BatchNorm + LeakyReLU(slope); ``replicate`` = 4 when ``x`` is the low-resolution source of a nearest x2
+        upsampled tensor that the reference would have normalised (identical statistics, a quarter of the traffic)."""
+        return self._run(x, slope, replicate)
 
 
 def run_layers(seq, x, residual=None):

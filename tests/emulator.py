@@ -97,11 +97,11 @@ class Emulator:
     def bn_workspace(self, B, C, HW):
         return 16
 
-    def bn_train_stats(self, x, mean, invstd, rm, rv, nbt, momentum, eps, ws, B, C, HW):
+    def bn_train_stats(self, x, mean, invstd, rm, rv, nbt, momentum, eps, ws, B, C, HW, replicate=1):
         if nbt is not None:
             nbt.add_(1)
         xv = _v(x, B, C, HW)
-        n = B * HW
+        n = B * HW * replicate
         m = xv.mean((0, 2))
         var = xv.var((0, 2), unbiased=False)
         mean.copy_(m)
@@ -111,8 +111,8 @@ class Emulator:
             rv.mul_(1 - momentum).add_(momentum * var * (n / max(n - 1, 1)))
         return 0
 
-    def bn_train_fwd(self, x, mean, invstd, rm, rv, nbt, gamma, beta, slope, momentum, eps, z, ws, B, C, HW):
-        self.bn_train_stats(x, mean, invstd, rm, rv, nbt, momentum, eps, ws, B, C, HW)
+    def bn_train_fwd(self, x, mean, invstd, rm, rv, nbt, gamma, beta, slope, momentum, eps, z, ws, B, C, HW, replicate=1):
+        self.bn_train_stats(x, mean, invstd, rm, rv, nbt, momentum, eps, ws, B, C, HW, replicate)
         return self.bn_act_fwd(x, mean, invstd, gamma, beta, slope, z, B, C, HW)
 
     def bn_eval_stats(self, rm, rv, mean, invstd, eps, C):

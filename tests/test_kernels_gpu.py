@@ -164,10 +164,13 @@ def test_batchnorm_all_passes(K, shape):
     ws = workspace(K.bn_workspace(B, C, HW))
     mean, invstd = torch.zeros(C), torch.zeros(C)
     nbt = torch.tensor(41, dtype=torch.int64)
-    run_both(K, 'bn_train_stats', [x, mean, invstd, rm, rv, nbt, 0.1, 1e-5, ws, B, C, HW], [1, 2, 3, 4, 5], tol=1e-5)
+    run_both(K, 'bn_train_stats', [x, mean, invstd, rm, rv, nbt, 0.1, 1e-5, ws, B, C, HW, 1], [1, 2, 3, 4, 5], tol=1e-5)
+    run_both(K, 'bn_train_stats', [x, mean, invstd, rm, rv, nbt, 0.1, 1e-5, ws, B, C, HW, 4], [1, 2, 3, 4, 5], tol=1e-5)
     run_both(K, 'bn_train_fwd', [x, torch.zeros(C), torch.zeros(C), rm, rv, nbt, gamma, beta, 0.2, 0.1, 1e-5,
-                                 torch.zeros(B, C, HW), ws, B, C, HW], [1, 2, 3, 4, 5, 11], tol=1e-5)
-    E.bn_train_stats(x, mean, invstd, None, None, None, 0.1, 1e-5, None, B, C, HW)
+                                 torch.zeros(B, C, HW), ws, B, C, HW, 1], [1, 2, 3, 4, 5, 11], tol=1e-5)
+    run_both(K, 'bn_train_fwd', [x, torch.zeros(C), torch.zeros(C), rm, rv, nbt, gamma, beta, 0.2, 0.1, 1e-5,
+                                 torch.zeros(B, C, HW), ws, B, C, HW, 4], [1, 2, 3, 4, 5, 11], tol=1e-5)
+    E.bn_train_stats(x, mean, invstd, None, None, None, 0.1, 1e-5, None, B, C, HW, 1)
     run_both(K, 'bn_eval_stats', [rm, rv, torch.zeros(C), torch.zeros(C), 1e-5, C], [2, 3], tol=1e-6)
     for slope in (0.2, 1.0):
         run_both(K, 'bn_act_fwd', [x, mean, invstd, gamma, beta, slope, torch.zeros(B, C, HW), B, C, HW], [6], tol=1e-5)

@@ -14,5 +14,5 @@ for spec in sys.argv[1:]:
     ws = torch.empty(K.conv2d_wgrad_workspace(B, Cin, Cout, H, H, ks) // 4 + 4, device='cuda')
     for _ in range(5):
         K.conv2d_fwd(x, w, bias, None, y, B, Cin, Cout, H, H, ks)
-        K.conv2d_wgrad(x, gy, gw, gb, ws, ws.numel() * 4, B, Cin, Cout, H, H, ks, 0)
+        pass
     torch.cuda.synchronize()

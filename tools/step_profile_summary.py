@@ -1,6 +1,6 @@
 """Dev tool: per-kernel GPU time of steady-state graph replay from a rocprofv3 --kernel-trace CSV of bench.py."""
-import csv, glob, re, collections, sys
-p = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+import csv, glob, os, re, collections, sys
+p = max(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(p)))
 names = [r['Kernel_Name'] for r in rows]
 idx = [i for i, n in enumerate(names) if 'ema_kernel' in n]
