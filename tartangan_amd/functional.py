@@ -255,6 +255,66 @@ def conv2d(x, weight, bias=None, residual=None):
 
 
 # =========================================================================== GEMM
+class _UpConv3x3(Function):
+    """conv3x3(nearest_up2x(a)) + bias [+ residual] as four 2x2-tap convolutions at the low resolution
+    (tg_upconv3x3_*): 2.25x fewer FLOPs than the reference's up -> conv, and the upsampled tensor is never written in
+    the forward pass."""
+
+    @staticmethod
+    def forward(ctx, a, w, bias, residual=None):
+        a, w = a.contiguous(), w.contiguous()
+        B, Cin, H, W = a.shape
+        Cout = w.shape[0]
+        if w.shape[2:] != (3, 3):
+            raise RuntimeError('upconv3x3 needs a 3x3 filter')
+        wp = a.new_empty(4, Cout, Cin, 2, 2)
+        K().upconv3x3_weights(w, wp, Cout, Cin)
+        if residual is not None:
+            residual = residual.contiguous()
+        y = a.new_empty(B, Cout, 2 * H, 2 * W)
+        K().upconv3x3_fwd(a, wp, bias, residual, y, B, Cin, Cout, H, W)
+        ctx.save_for_backward(a, w, bias)
+        ctx.has_residual = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        a, w, bias = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gres = gy if ctx.has_residual and need[3] else None
+        if torch.is_grad_enabled():
+            # double backward requested: rebuild from the twice-differentiable primitives
+            with torch.enable_grad():
+                y = conv2d(upsample_nearest2x(a), w, bias)
+            inputs = [t for t, n in zip((a, w, bias), need[:3]) if n and t is not None]
+            got = iter(torch.autograd.grad(y, inputs, gy, create_graph=True))
+            ga, gw, gb = (next(got) if (n and t is not None) else None for t, n in zip((a, w, bias), need[:3]))
+            return ga, gw, gb, gres
+        gy = gy.contiguous()
+        ga = gw = gb = None
+        if need[0]:
+            ga = _Pool2.apply(_ConvDgrad.apply(gy, w), 1.0)
+        need_w = need[1] and _param_grads_wanted()
+        need_b = bias is not None and need[2] and _param_grads_wanted()
+        if need_w:
+            au = upsample_nearest2x(a)
+            sink_w, sink_b = _grad_sink(w), _grad_sink(bias)
+            if sink_w is not None and (not need_b or sink_b is not None):
+                _conv_wgrad_into(au, gy, sink_w, sink_b if need_b else None, 3, accumulate=1)
+            else:
+                gw = _ConvWgrad.apply(au, gy, 3)
+                if need_b:
+                    gb = _ChannelSum.apply(gy)
+        elif need_b:
+            gb = _ChannelSum.apply(gy)
+        return ga, gw, gb, gres
+
+
+def upconv3x3(a, weight, bias=None, residual=None):
+    """conv2d(F.interpolate(a, scale_factor=2), weight, bias, padding=1) [+ residual]"""
+    return _UpConv3x3.apply(a, weight, bias, residual)
+
+
 class _Gemm(Function):
     """C = op(A) op(B); A,B 2-D or batched 3-D row-major."""
 

@@ -28,6 +28,31 @@ class Emulator:
         y.copy_(r if residual is None else _v(residual, B, Cout, H, W) + r)
         return 0
 
+    def upconv3x3_weights(self, w, wp, Cout, Cin):
+        k = _v(w, Cout, Cin, 3, 3)
+        out = _v(wp, 4, Cout, Cin, 2, 2)
+        for dy in range(2):
+            rows = [k[:, :, 0], k[:, :, 1] + k[:, :, 2]] if dy == 0 else [k[:, :, 0] + k[:, :, 1], k[:, :, 2]]
+            for dx in range(2):
+                for ty in range(2):
+                    r = rows[ty]
+                    cols = [r[:, :, 0], r[:, :, 1] + r[:, :, 2]] if dx == 0 else [r[:, :, 0] + r[:, :, 1], r[:, :, 2]]
+                    out[dy * 2 + dx, :, :, ty, 0] = cols[0]
+                    out[dy * 2 + dx, :, :, ty, 1] = cols[1]
+        return 0
+
+    def upconv3x3_fwd(self, a, wp, bias, residual, y, B, Cin, Cout, H, W):
+        ap = F.pad(_v(a, B, Cin, H, W), (1, 1, 1, 1))
+        out = _v(y, B, Cout, 2 * H, 2 * W)
+        res = None if residual is None else _v(residual, B, Cout, 2 * H, 2 * W)
+        k = _v(wp, 4, Cout, Cin, 2, 2)
+        for dy in range(2):
+            for dx in range(2):
+                full = F.conv2d(ap, k[dy * 2 + dx], bias)             # (H+1) x (W+1): window starting at row i'-1
+                r = full[:, :, dy:dy + H, dx:dx + W]
+                out[:, :, dy::2, dx::2] = r if res is None else res[:, :, dy::2, dx::2] + r
+        return 0
+
     def conv2d_dgrad(self, gy, w, gx, B, Cin, Cout, H, W, ks):
         gx.copy_(F.conv_transpose2d(_v(gy, B, Cout, H, W), _v(w, Cout, Cin, ks, ks), padding=ks // 2))
         return 0

@@ -72,6 +72,27 @@ def test_conv_fwd(K, shape):
     run_both(K, 'conv2d_fwd', [x, w, b, rnd(B, Cout, H, W, seed=7), torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, ks], [4], tol=2e-5)
 
 
+UPCONV_SHAPES = [(2, 16, 16, 16, 16), (3, 8, 20, 8, 8), (2, 32, 16, 64, 64), (4, 128, 128, 4, 4), (2, 128, 64, 16, 16), (2, 5, 7, 6, 10),
+                 (8, 64, 32, 32, 32), (1, 16, 3, 33, 20), (64, 128, 128, 4, 4)]
+
+
+@pytest.mark.parametrize('shape', UPCONV_SHAPES)
+def test_upconv3x3(K, shape):
+    """conv3x3(up2x(a)) as four low-resolution 2x2-tap phases == the reference's formulation."""
+    B, Cin, Cout, H, W = shape
+    a, w, b = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, scale=0.2), rnd(Cout)
+    wp = torch.zeros(4, Cout, Cin, 2, 2)
+    run_both(K, 'upconv3x3_weights', [w, wp, Cout, Cin], [1], tol=1e-6)
+    E.upconv3x3_weights(w, wp, Cout, Cin)
+    y = torch.zeros(B, Cout, 2 * H, 2 * W)
+    run_both(K, 'upconv3x3_fwd', [a, wp, b, None, y, B, Cin, Cout, H, W], [4], tol=3e-5)
+    run_both(K, 'upconv3x3_fwd', [a, wp, None, rnd(B, Cout, 2 * H, 2 * W, seed=7), y, B, Cin, Cout, H, W], [4], tol=3e-5)
+    # and against the textbook formulation
+    E.upconv3x3_fwd(a, wp, b, None, y, B, Cin, Cout, H, W)
+    want = torch.nn.functional.conv2d(torch.nn.functional.interpolate(a, scale_factor=2), w, b, padding=1)
+    assert torch.allclose(y, want, rtol=1e-4, atol=1e-4)
+
+
 def test_conv_fwd_exact_integer_layout(K):
     """Asymmetric small-integer data: any A/B/C fragment transposition shows up as an exact mismatch."""
     B, Cin, Cout, H, W = 2, 8, 32, 32, 32
