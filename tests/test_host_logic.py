@@ -137,6 +137,45 @@ def test_deferred_wgrad_never_reduces_one_gradient_twice_in_a_launch():
     assert torch.allclose(deferred, tr2.optimizer_d.grads, rtol=1e-6, atol=1e-6)
 
 
+def test_r1_first_order_pass_skips_parameter_gradients_without_changing_results():
+    """models.losses.gradient_penalty runs its autograd.grad under TF.input_grads_only(): same gp, same D gradients,
+    but no weight-gradient kernels in that pass."""
+    fx = load_golden('c32a2_cnn_b8')
+    imgs = synthetic_images(fx['batch'], 32, 7)
+
+    class Counting(Emulator):
+        wgrads = 0
+
+        def conv2d_wgrad(self, *a):
+            Counting.wgrads += 1
+            return super().conv2d_wgrad(*a)
+
+        def conv2d_wgrad_partials(self, *a):
+            Counting.wgrads += 1
+            return super().conv2d_wgrad_partials(*a)
+
+    def run(hint):
+        backend._set_backend_for_testing(Counting())
+        Counting.wgrads = 0
+        tr = make_trainer(fx)
+        torch.manual_seed(1)
+        import contextlib
+        orig = TF.input_grads_only
+        if not hint:
+            TF.input_grads_only = contextlib.nullcontext
+        try:
+            d_loss, gp = tr._d_phase(imgs)
+        finally:
+            TF.input_grads_only = orig
+        return float(d_loss), float(gp), tr.optimizer_d.grads.clone(), Counting.wgrads
+
+    a, b = run(True), run(False)
+    assert a[0] == b[0] and a[1] == b[1]
+    assert torch.allclose(a[2], b[2], rtol=1e-6, atol=1e-7)
+    n_convs = sum(1 for m in make_trainer(fx).d.modules() if type(m).__name__ == 'Conv2d')
+    assert b[3] - a[3] == n_convs           # exactly one wasted weight gradient per discriminator conv is gone
+
+
 def test_product_has_no_cpu_fallback():
     backend._set_backend_for_testing(None)
     x = torch.zeros(1, 4, 4, 4)
