@@ -78,7 +78,8 @@ class KernelTimer:
                      'bn_act_dbwd', 'gemm', 'softmax_fwd', 'softmax_bwd', 'softmax_dbwd', 'up2x', 'pool2',
                      'bilinear_half_fwd', 'bilinear_half_bwd', 'add', 'channel_sum', 'adam_step', 'ema', 'attn_fwd', 'attn_bwd', 'bn_train_fwd',
                      'maxpool2_fwd', 'maxpool2_bwd', 'scale_add_dev', 'dot', 'scale_dev', 'mul', 'lrelu_bwd', 'tanh_fwd', 'tanh_bwd',
-                     'row_sum', 'row_bcast', 'bce_logits', 'sumsq', 'fill', 'scale', 'channel_bcast'):
+                     'row_sum', 'row_bcast', 'bce_logits', 'sumsq', 'fill', 'scale', 'channel_bcast', 'conv2d_wgrad_partials',
+                     'conv2d_wgrad_reduce_batch', 'upconv3x3_fwd', 'upconv3x3_weights'):
             fn = getattr(self.K, name)
             self._saved[name] = fn
             setattr(self.K, name, self._wrap(name, fn))
@@ -126,6 +127,9 @@ class KernelTimer:
                 nbytes = 4.0 * (B * Cin * H * W + B * Cout * H * W + Cin * Cout * ks * ks)
                 if name == 'conv2d_fwd' and args[3] is not None:
                     nbytes += 4.0 * B * Cout * H * W          # fused residual read
+            if name == 'upconv3x3_fwd':           # (a, wp, bias, residual, y, B, Cin, Cout, H, W): 16 taps per source pixel
+                B, Cin, Cout, H, W = args[5:10]
+                flops = 2.0 * B * Cin * Cout * H * W * 16
             d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             d['ms'] += ms
             d['launches'] += 1
@@ -135,7 +139,8 @@ class KernelTimer:
 
 
 # where (B, Cin, Cout, H, W, ks) sit in each conv entry point's argument list (include/tartangan_amd.h)
-CONV_DIMS = {'conv2d_fwd': slice(5, 11), 'conv2d_dgrad': slice(3, 9), 'conv2d_wgrad': slice(6, 12)}
+CONV_DIMS = {'conv2d_fwd': slice(5, 11), 'conv2d_dgrad': slice(3, 9), 'conv2d_wgrad': slice(6, 12),
+             'conv2d_wgrad_partials': slice(4, 10)}
 
 
 def hbm_traffic_per_launch(a, agg):

@@ -848,6 +848,110 @@ __global__ void __launch_bounds__(256) upconv_weights_kernel(const float* __rest
     }
 }
 
+// All four phases in ONE kernel: the low-resolution patch is staged once, every (row, column) position of the 3x3 halo
+// is read once per k-group and feeds the phases whose 2x2 window covers it (16 (phase, tap) products per channel), each
+// phase into its own accumulators; the epilogue writes the two horizontally adjacent phases as one float2.  16-channel
+// output tiles (64 accumulator registers per lane).
+template <class G>
+__global__ void __launch_bounds__(CT_THREADS)
+conv_upfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                  const float* __restrict__ residual, float* __restrict__ y, Shape s, int vec_x, int vec_w) {
+  constexpr int KS = 2, CT = 16, NT = 4, KG = 4;
+  using P = Patch<G, KS>;
+  using WT = WTile<KS, CT, false>;
+  constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS, NG = CK / KG;
+  static_assert(G::NPIX == 256 && KK == 4, "256-pixel tiles, 2x2 windows");
+  __shared__ __attribute__((aligned(16))) float lds[CK * P::CIS + 4 * WT::SIZE];
+  float* pl = lds;
+  float* wl = lds + CK * P::CIS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, h = lane >> 4;
+  const TileCoord tc = decode_tile<G>(blockIdx.x, s.H, s.W);
+  const int co0 = blockIdx.y * CT;
+  const int pix0 = wave * 64;
+  int lane_b[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) lane_b[n] = h * P::CIS + pix_off<G, KS>(pix0 + n * 16 + j);
+  const int lane_a = (h * KK) * CTS + j;
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[ph][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  PatchStager<G, KS, CK> ps;
+  WeightStager<KS, CT, false, false> ws[4];
+  const size_t phase_stride = (size_t)s.Cout * s.Cin * KK;
+  ps.load(x, s, s.Cin, 0, tc, vec_x);
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) ws[ph].load(wp + ph * phase_stride, s.Cin, s.Cout, 0, co0, vec_w);
+  for (int ci0 = 0; ci0 < s.Cin; ci0 += CK) {
+    __syncthreads();
+    ps.store(pl);
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) ws[ph].store(wl + ph * WT::SIZE);
+    __syncthreads();
+    if (ci0 + CK < s.Cin) {
+      ps.load(x, s, s.Cin, ci0 + CK, tc, vec_x);
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) ws[ph].load(wp + ph * phase_stride, s.Cin, s.Cout, ci0 + CK, co0, vec_w);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float b[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b[n] = pl[lane_b[n] + (g * KG) * P::CIS + kh * P::PWS + kw];
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+              const int ty = kh - dy, tx = kw - dx;            // this position inside phase (dy, dx)'s window?
+              if (ty < 0 || ty > 1 || tx < 0 || tx > 1) continue;
+              const float a = wl[(dy * 2 + dx) * WT::SIZE + lane_a + ((g * KG) * KK + ty * 2 + tx) * CTS];
+#pragma unroll
+              for (int n = 0; n < NT; ++n)
+                acc[dy * 2 + dx][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[dy * 2 + dx][n], 0, 0, 0);
+            }
+        }
+  }
+
+  // epilogue: y[b][co][2(h0+pr)+dy][2(w0+pc)+dx]; the dx pair of a lane is one aligned float2
+  const int W2 = 2 * s.W;
+  const uint32_t HW2 = (uint32_t)(2 * s.H * W2);
+  const int64_t tile0 = ((((int64_t)tc.b0 * s.Cout + co0) * (2 * s.H) + 2 * tc.h0) * W2 + 2 * tc.w0) * 4;
+  char* ybase = reinterpret_cast<char*>(y) + tile0;
+  const char* rbase = reinterpret_cast<const char*>(residual) + tile0;
+  float bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = bias ? bias[min(co0 + 4 * h + r, s.Cout - 1)] : 0.f;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int p = pix0 + n * 16 + j;
+    const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
+    const int pr = rem / G::TW, pc = rem % G::TW;
+    if (tc.b0 + img >= s.B || tc.h0 + pr >= s.H || tc.w0 + pc >= s.W) continue;
+    const uint32_t lane_off = __umul24(__umul24(img, s.Cout) + 4 * h, HW2) + __umul24(2 * pr, W2) + 2 * pc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (co0 + 4 * h + r >= s.Cout) continue;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const uint32_t off = (lane_off + (uint32_t)r * HW2 + (uint32_t)(dy * W2)) << 2;
+        float2 o = make_float2(acc[dy * 2][n][r] + bv[r], acc[dy * 2 + 1][n][r] + bv[r]);
+        if (residual) {
+          const float2 rr = *reinterpret_cast<const float2*>(rbase + off);
+          o.x += rr.x; o.y += rr.y;
+        }
+        *reinterpret_cast<float2*>(ybase + off) = o;
+      }
+    }
+  }
+}
+
 // =========================================================================== host dispatch
 enum GeoId { GEO_4, GEO_8, GEO_16, GEO_X };
 static inline GeoId pick_geo(int H, int W) {
@@ -996,6 +1100,20 @@ int tg_upconv3x3_fwd(const float* a, const float* wp, const float* bias, const f
   TG_CHECK_PTR(a); TG_CHECK_PTR(wp); TG_CHECK_PTR(y);
   if (int rc = check_shape(B, Cin, Cout, 2 * H, 2 * W, 3)) return rc;      // the output plane is the large one
   hipStream_t st = tg_stream(stream);
+  {
+    // one kernel for all four phases when the low-resolution plane gives enough 256-pixel tiles
+    Shape s{B, Cin, Cout, H, W};
+    const GeoId g = pick_geo(H, W);
+    const int cot = (Cout + 15) / 16;
+    const bool aligned8 = (((uintptr_t)y & 7) == 0) && (!residual || ((uintptr_t)residual & 7) == 0);
+    if ((g == GEO_16 || g == GEO_X) && aligned8 && (int64_t)geo_tiles(g, B, H, W) * cot >= 256) {
+      const int vx = plane_vec_ok(a, W), vw = tg_aligned16(wp);
+      dim3 grid(geo_tiles(g, B, H, W), cot);
+      if (g == GEO_16) conv_upfwd_kernel<G16><<<grid, CT_THREADS, 0, st>>>(a, wp, bias, residual, y, s, vx, vw);
+      else conv_upfwd_kernel<GX><<<grid, CT_THREADS, 0, st>>>(a, wp, bias, residual, y, s, vx, vw);
+      return tg_launch_status();
+    }
+  }
   for (int ph = 0; ph < 4; ++ph) {
     Shape s{B, Cin, Cout, H, W};
     s.oy = s.py = ph >> 1;

@@ -310,6 +310,16 @@ class _UpConv3x3(Function):
         return ga, gw, gb, gres
 
 
+def upconv3x3_pays(a, weight):
+    """True where tg_upconv3x3_fwd runs as ONE kernel (>= 256 workgroups of 256 low-resolution pixels x 16 output
+    channels on planes of 16x16 or more); smaller layers are faster as up2x + the 3x3 kernel."""
+    B, _, H, W = a.shape
+    if H < 16 or W < 16 or (H, W) in ((4, 4), (8, 8)):
+        return False
+    tiles = B if (H, W) == (16, 16) else B * ((H + 7) // 8) * ((W + 31) // 32)
+    return tiles * ((weight.shape[0] + 15) // 16) >= 256
+
+
 def upconv3x3(a, weight, bias=None, residual=None):
     """conv2d(F.interpolate(a, scale_factor=2), weight, bias, padding=1) [+ residual]"""
     return _UpConv3x3.apply(a, weight, bias, residual)

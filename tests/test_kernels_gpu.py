@@ -73,7 +73,9 @@ def test_conv_fwd(K, shape):
 
 
 UPCONV_SHAPES = [(2, 16, 16, 16, 16), (3, 8, 20, 8, 8), (2, 32, 16, 64, 64), (4, 128, 128, 4, 4), (2, 128, 64, 16, 16), (2, 5, 7, 6, 10),
-                 (8, 64, 32, 32, 32), (1, 16, 3, 33, 20), (64, 128, 128, 4, 4)]
+                 (8, 64, 32, 32, 32), (1, 16, 3, 33, 20), (64, 128, 128, 4, 4),
+                 # enough low-resolution tiles for the all-phases-in-one kernel (aligned, 16x16 planes, ragged)
+                 (16, 32, 16, 64, 64), (128, 8, 24, 16, 16), (20, 12, 10, 70, 50), (64, 64, 32, 32, 32)]
 
 
 @pytest.mark.parametrize('shape', UPCONV_SHAPES)
