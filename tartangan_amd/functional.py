@@ -453,6 +453,7 @@ class _BNActBwd(Function):
         K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, slope, int(training), gx, gg, gb, ws, B, C, hw, 0)
         ctx.save_for_backward(gz, x, gamma, beta, mean, invstd)
         ctx.slope, ctx.training = slope, training
+        ctx.set_materialize_grads(False)        # the R1 pass never differentiates ggamma / gbeta: no zero fills for them
         return gx, gg, gb
 
     @staticmethod
@@ -466,8 +467,10 @@ class _BNActBwd(Function):
         a_gz, a_x = torch.empty_like(x), torch.empty_like(x)
         a_gamma = x.new_empty(C)
         ws = _ws(x, K().bn_workspace(B, C, hw))
-        K().bn_act_dbwd(v.contiguous(), vg.contiguous(), vb.contiguous(), gz, x, mean, invstd, gamma, beta,
-                        ctx.slope, a_gz, a_x, a_gamma, ws, B, C, hw)
+        if v is None:
+            v = torch.zeros_like(x)
+        K().bn_act_dbwd(v.contiguous(), None if vg is None else vg.contiguous(), None if vb is None else vb.contiguous(),
+                        gz, x, mean, invstd, gamma, beta, ctx.slope, a_gz, a_x, a_gamma, ws, B, C, hw)
         return a_gz, a_x, a_gamma, None, None, None, None, None, None
 
 
