@@ -51,6 +51,13 @@ int tg_conv2d_fwd(const float* x, const float* w, const float* bias /*nullable*/
 int tg_upconv3x3_weights(const float* w, float* wp, int Cout, int Cin, void* stream);
 int tg_upconv3x3_fwd(const float* a, const float* wp, const float* bias /*nullable*/, const float* residual /*nullable*/,
                      float* y, int B, int Cin, int Cout, int H, int W, void* stream);
+/* gradient of tg_upconv3x3_fwd w.r.t. its low-resolution input (what autograd computes as pool2x2sum(dgrad3x3(gy))):
+ * a 4x4-tap stride-2 convolution over gy (B,Cout,2H,2W) with w4t [Cin][Cout][4][4] from tg_upconv3x3_weights_t.
+ * Only where the low-resolution plane gives >= 256 workgroups (tg_upconv3x3_dgrad_supported); callers fall back to
+ * tg_conv2d_dgrad + tg_pool2 otherwise.                                                                    */
+int tg_upconv3x3_weights_t(const float* w, float* w4t, int Cout, int Cin, void* stream);
+int tg_upconv3x3_dgrad_supported(int B, int Cin, int Cout, int H, int W);
+int tg_upconv3x3_dgrad(const float* gy, const float* w4t, float* ga, int B, int Cin, int Cout, int H, int W, void* stream);
 /* gx = d/dx: correlation of gy with the transposed, spatially flipped filter
  * (what autograd's convolution_backward computes for grad_input)              */
 int tg_conv2d_dgrad(const float* gy, const float* w, float* gx,

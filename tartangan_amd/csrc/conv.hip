@@ -214,7 +214,8 @@ struct PatchStager {
 // LDS: wl[(ci*KK + tap)][co], row stride CTS.  ROWLEN contiguous floats per source row:
 //   forward: row = co,  w[co][ci0..ci0+CK][tap]          (element k = ci*KK + tap)
 //   dgrad  : row = ci,  w[ci][co0..co0+CT][KK-1-tap]     (element k = co*KK + tp), w stored [Cin_eff][Cout_eff][KK]
-template <int KS, bool WK> struct FwdCfg { static constexpr int CK = (KS == 3) ? (WK ? 16 : 8) : (KS == 2) ? (WK ? 32 : 16) : 32; };
+// (KS code 4: the 16-tap filter rows of the stride-2 transpose kernel, conv_upT_kernel; it only uses the filter stager)
+template <int KS, bool WK> struct FwdCfg { static constexpr int CK = (KS == 3) ? (WK ? 16 : 8) : (KS == 2) ? (WK ? 32 : 16) : (KS == 4) ? 8 : 32; };
 
 template <int KS, int CT, bool WK>
 struct WTile {
@@ -952,6 +953,166 @@ conv_upfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, con
   }
 }
 
+// Transpose of the above (gradient w.r.t. the low-resolution input; also what AvgPool2d(2) o conv3x3 is up to a filter
+// transform): a 4x4-tap STRIDE-2 convolution over the high-resolution tensor,
+//     ga[b][ci][i][j] = sum_co sum_{u,v in 0..3} w4t[ci][co][u][v] * gy[b][co][2i-1+u][2j-1+v],
+//     w4t[ci][co][u][v] = sum_{kh in S(u), kw in S(v)} w[co][ci][kh][kw],   S = {2}, {1,2}, {0,1}, {0}.
+// 16 products per source pixel and channel pair instead of 36 (3x3 dgrad at the high resolution) + a 2x2 sum.
+// Tile = 256 low-resolution pixels; the staged patch is the (2 TH + 2) x (2 TW + 2) high-resolution window.
+__global__ void __launch_bounds__(256) upconvT_weights_kernel(const float* __restrict__ w, float* __restrict__ w4t, int Cout, int Cin) {
+  const int e = blockIdx.x * 256 + threadIdx.x;          // e = ci * Cout + co
+  if (e >= Cout * Cin) return;
+  const int ci = e / Cout, co = e - ci * Cout;
+  float k[3][3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i / 3][i % 3] = w[((int64_t)co * Cin + ci) * 9 + i];
+  float r[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { r[0][c] = k[2][c]; r[1][c] = k[1][c] + k[2][c]; r[2][c] = k[0][c] + k[1][c]; r[3][c] = k[0][c]; }
+  float* o = w4t + (int64_t)e * 16;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { o[u * 4 + 0] = r[u][2]; o[u * 4 + 1] = r[u][1] + r[u][2]; o[u * 4 + 2] = r[u][0] + r[u][1]; o[u * 4 + 3] = r[u][0]; }
+}
+
+template <class G>
+struct Patch2x {                       // high-resolution window of a low-resolution tile
+  static constexpr int PH = 2 * G::TH + 2, TW2 = 2 * G::TW;
+  static constexpr int IOFF = 4, ORG = IOFF - 1;
+  static constexpr int PWS = TW2 + 2 * IOFF;
+  static constexpr int RAW = PH * PWS;
+  static constexpr int CIS = ((RAW + 31) / 32) * 32 + 16;
+  static_assert(G::NI == 1, "single-image tiles");
+};
+
+template <class G, int CK>
+struct PatchStager2x {
+  using P = Patch2x<G>;
+  static constexpr int Q = P::TW2 / 4;
+  static constexpr int ROWS = CK * P::PH;
+  static constexpr int NV = (ROWS * Q + CT_THREADS - 1) / CT_THREADS;
+  static constexpr int NHALO = ROWS * 2;
+  static constexpr int NH = (NHALO + CT_THREADS - 1) / CT_THREADS;
+  float4 v[NV];
+  float hv[NH];
+  // gy: (B, C, 2H, 2W); tile (b0, h0, w0) in low-resolution coordinates; window rows 2 h0 - 1 .., columns 2 w0 - 1 ..
+  __device__ __forceinline__ void load(const float* __restrict__ gy, int B, int C, int H2, int W2, int c0, const TileCoord& tc, bool vec) {
+    const char* base = reinterpret_cast<const char*>(gy) + ((((int64_t)tc.b0 * C + c0) * H2 + (2 * tc.h0 - 1)) * W2 + (2 * tc.w0 - 1)) * 4;
+    const uint32_t HW2 = (uint32_t)(H2 * W2);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + i * CT_THREADS;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < ROWS * Q) {
+        const int q = e % Q, row = e / Q;
+        const int r = row % P::PH, ci = row / P::PH;
+        const int hh = 2 * tc.h0 - 1 + r, ww = 2 * tc.w0 + 4 * q;
+        const uint32_t off = (__umul24(ci, HW2) + __umul24(r, W2) + 1 + 4 * q) << 2;
+        if (c0 + ci < C && hh >= 0 && hh < H2 && ww < W2) {
+          const char* p = base + off;
+          if (vec) {
+            val = *reinterpret_cast<const float4*>(p);
+          } else {
+            val.x = *reinterpret_cast<const float*>(p);
+            if (ww + 1 < W2) val.y = *reinterpret_cast<const float*>(p + 4);
+            if (ww + 2 < W2) val.z = *reinterpret_cast<const float*>(p + 8);
+            if (ww + 3 < W2) val.w = *reinterpret_cast<const float*>(p + 12);
+          }
+        }
+      }
+      v[i] = val;
+    }
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int e = threadIdx.x + i * CT_THREADS;
+      float val = 0.f;
+      if (e < NHALO) {
+        const int row = e >> 1;
+        const int r = row % P::PH, ci = row / P::PH;
+        const int hh = 2 * tc.h0 - 1 + r;
+        const int ww = (e & 1) ? 2 * tc.w0 + P::TW2 : 2 * tc.w0 - 1;
+        if (c0 + ci < C && hh >= 0 && hh < H2 && ww >= 0 && ww < W2)
+          val = *reinterpret_cast<const float*>(base + ((__umul24(ci, HW2) + __umul24(r, W2) + ((e & 1) ? P::TW2 + 1 : 0)) << 2));
+      }
+      hv[i] = val;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = threadIdx.x + i * CT_THREADS;
+      if (e < ROWS * Q) {
+        const int q = e % Q, row = e / Q;
+        const int r = row % P::PH, ci = row / P::PH;
+        *reinterpret_cast<float4*>(lds + ci * P::CIS + r * P::PWS + P::IOFF + 4 * q) = v[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int e = threadIdx.x + i * CT_THREADS;
+      if (e < NHALO) {
+        const int row = e >> 1;
+        const int r = row % P::PH, ci = row / P::PH;
+        lds[ci * P::CIS + r * P::PWS + ((e & 1) ? P::IOFF + P::TW2 : P::IOFF - 1)] = hv[i];
+      }
+    }
+  }
+};
+
+template <class G>
+__global__ void __launch_bounds__(CT_THREADS)
+conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, float* __restrict__ ga, Shape s /*Cin = gy channels,
+                Cout = ga channels, H x W = ga plane*/, int vec_x, int vec_w) {
+  constexpr int CT = 16, NT = 4, KG = 4;
+  using P = Patch2x<G>;
+  using WT = WTile<4, CT, false>;                     // 16 taps per (out, in) channel pair
+  constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS, NG = CK / KG;
+  static_assert(KK == 16 && G::NPIX == 256, "16 taps, 256-pixel tiles");
+  __shared__ __attribute__((aligned(16))) float lds[CK * P::CIS + WT::SIZE];
+  float* pl = lds;
+  float* wl = lds + CK * P::CIS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, h = lane >> 4;
+  const TileCoord tc = decode_tile<G>(blockIdx.x, s.H, s.W);
+  const int co0 = blockIdx.y * CT;
+  const int pix0 = wave * 64;
+  int lane_b[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int p = pix0 + n * 16 + j;
+    lane_b[n] = h * P::CIS + (2 * (p / G::TW)) * P::PWS + 2 * (p % G::TW) + P::ORG;
+  }
+  const int lane_a = (h * KK) * CTS + j;
+  using Core = FwdCore<G, 3, 16, 1, false>;
+  typename Core::acc_t acc[1][NT];
+  Core::zero(acc);
+
+  PatchStager2x<G, CK> ps;
+  WeightStager<4, CT, false, false> ws;
+  const int H2 = 2 * s.H, W2 = 2 * s.W;
+  ps.load(gy, s.B, s.Cin, H2, W2, 0, tc, vec_x);
+  ws.load(w4t, s.Cin, s.Cout, 0, co0, vec_w);
+  for (int ci0 = 0; ci0 < s.Cin; ci0 += CK) {
+    __syncthreads();
+    ps.store(pl);
+    ws.store(wl);
+    __syncthreads();
+    if (ci0 + CK < s.Cin) {
+      ps.load(gy, s.B, s.Cin, H2, W2, ci0 + CK, tc, vec_x);
+      ws.load(w4t, s.Cin, s.Cout, ci0 + CK, co0, vec_w);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float a = wl[lane_a + ((g * KG) * KK + t) * CTS];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[lane_b[n] + (g * KG) * P::CIS + (t >> 2) * P::PWS + (t & 3)], acc[0][n], 0, 0, 0);
+      }
+  }
+  Core::epilogue(acc, nullptr, nullptr, ga, s, tc, co0, pix0, j, h, wave);
+}
+
 // =========================================================================== host dispatch
 enum GeoId { GEO_4, GEO_8, GEO_16, GEO_X };
 static inline GeoId pick_geo(int H, int W) {
@@ -1122,6 +1283,32 @@ int tg_upconv3x3_fwd(const float* a, const float* wp, const float* bias, const f
     if (int rc = launch_fwd<2, false>(a, wp + (size_t)ph * Cout * Cin * 4, bias, residual, y, s, st)) return rc;
   }
   return TG_OK;
+}
+
+int tg_upconv3x3_weights_t(const float* w, float* w4t, int Cout, int Cin, void* stream) {
+  TG_CHECK_PTR(w); TG_CHECK_PTR(w4t); TG_CHECK_POS(Cout); TG_CHECK_POS(Cin);
+  upconvT_weights_kernel<<<(Cout * Cin + 255) / 256, 256, 0, tg_stream(stream)>>>(w, w4t, Cout, Cin);
+  return tg_launch_status();
+}
+
+int tg_upconv3x3_dgrad_supported(int B, int Cin, int Cout, int H, int W) {
+  const GeoId g = pick_geo(H, W);
+  return (g == GEO_16 || g == GEO_X) && check_shape(B, Cin, Cout, 2 * H, 2 * W, 3) == TG_OK &&
+         (int64_t)geo_tiles(g, B, H, W) * ((Cin + 15) / 16) >= 256;
+}
+
+int tg_upconv3x3_dgrad(const float* gy, const float* w4t, float* ga, int B, int Cin, int Cout, int H, int W, void* stream) {
+  TG_CHECK_PTR(gy); TG_CHECK_PTR(w4t); TG_CHECK_PTR(ga);
+  if (!tg_upconv3x3_dgrad_supported(B, Cin, Cout, H, W)) return TG_EUNSUPPORTED;
+  // a convolution whose input channels are the forward's Cout (gy) and output channels its Cin (ga)
+  Shape s{B, Cout, Cin, H, W};
+  const GeoId g = pick_geo(H, W);
+  dim3 grid(geo_tiles(g, B, H, W), (Cin + 15) / 16);
+  const int vx = plane_vec_ok(gy, 2 * W), vw = tg_aligned16(w4t);
+  hipStream_t st = tg_stream(stream);
+  if (g == GEO_16) conv_upT_kernel<G16><<<grid, CT_THREADS, 0, st>>>(gy, w4t, ga, s, vx, vw);
+  else conv_upT_kernel<GX><<<grid, CT_THREADS, 0, st>>>(gy, w4t, ga, s, vx, vw);
+  return tg_launch_status();
 }
 
 int tg_conv2d_dgrad(const float* gy, const float* w, float* gx, int B, int Cin, int Cout, int H, int W, int ks, void* stream) {

@@ -293,7 +293,16 @@ class _UpConv3x3(Function):
         gy = gy.contiguous()
         ga = gw = gb = None
         if need[0]:
-            ga = _Pool2.apply(_ConvDgrad.apply(gy, w), 1.0)
+            B, Cin, H, W = a.shape
+            Cout = w.shape[0]
+            if K().upconv3x3_dgrad_supported(B, Cin, Cout, H, W):
+                # one 4x4-tap stride-2 pass over gy instead of dgrad3x3 at the high resolution + a 2x2 sum
+                w4t = a.new_empty(Cin, Cout, 4, 4)
+                K().upconv3x3_weights_t(w, w4t, Cout, Cin)
+                ga = torch.empty_like(a)
+                K().upconv3x3_dgrad(gy, w4t, ga, B, Cin, Cout, H, W)
+            else:
+                ga = _Pool2.apply(_ConvDgrad.apply(gy, w), 1.0)
         need_w = need[1] and _param_grads_wanted()
         need_b = bias is not None and need[2] and _param_grads_wanted()
         if need_w:

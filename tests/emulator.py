@@ -53,6 +53,26 @@ class Emulator:
                 out[:, :, dy::2, dx::2] = r if res is None else res[:, :, dy::2, dx::2] + r
         return 0
 
+    def upconv3x3_weights_t(self, w, w4t, Cout, Cin):
+        k = _v(w, Cout, Cin, 3, 3)
+        sets = [[2], [1, 2], [0, 1], [0]]
+        out = _v(w4t, Cin, Cout, 4, 4)
+        for u in range(4):
+            for v in range(4):
+                acc = 0
+                for kh in sets[u]:
+                    for kw in sets[v]:
+                        acc = acc + k[:, :, kh, kw]
+                out[:, :, u, v] = acc.t()
+        return 0
+
+    def upconv3x3_dgrad_supported(self, B, Cin, Cout, H, W):
+        return 1
+
+    def upconv3x3_dgrad(self, gy, w4t, ga, B, Cin, Cout, H, W):
+        _v(ga, B, Cin, H, W).copy_(F.conv2d(_v(gy, B, Cout, 2 * H, 2 * W), _v(w4t, Cin, Cout, 4, 4), stride=2, padding=1))
+        return 0
+
     def conv2d_dgrad(self, gy, w, gx, B, Cin, Cout, H, W, ks):
         gx.copy_(F.conv_transpose2d(_v(gy, B, Cout, H, W), _v(w, Cout, Cin, ks, ks), padding=ks // 2))
         return 0

@@ -95,6 +95,24 @@ def test_upconv3x3(K, shape):
     assert torch.allclose(y, want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('shape', [(16, 32, 16, 64, 64), (128, 32, 24, 16, 16), (20, 20, 10, 70, 50), (64, 64, 32, 32, 32), (8, 70, 9, 128, 32)])
+def test_upconv3x3_dgrad(K, shape):
+    """stride-2 4x4 transpose kernel == pool2x2sum(dgrad3x3(gy)) == autograd's gradient of conv3x3(up2x(a))."""
+    B, Cin, Cout, H, W = shape
+    assert K.upconv3x3_dgrad_supported(B, Cin, Cout, H, W)
+    w, gy = rnd(Cout, Cin, 3, 3, scale=0.2), rnd(B, Cout, 2 * H, 2 * W, seed=3)
+    w4t = torch.zeros(Cin, Cout, 4, 4)
+    run_both(K, 'upconv3x3_weights_t', [w, w4t, Cout, Cin], [1], tol=1e-6)
+    E.upconv3x3_weights_t(w, w4t, Cout, Cin)
+    ga = torch.zeros(B, Cin, H, W)
+    run_both(K, 'upconv3x3_dgrad', [gy, w4t, ga, B, Cin, Cout, H, W], [2], tol=5e-5)
+    E.upconv3x3_dgrad(gy, w4t, ga, B, Cin, Cout, H, W)
+    a = torch.zeros(B, Cin, H, W, requires_grad=True)
+    y = torch.nn.functional.conv2d(torch.nn.functional.interpolate(a, scale_factor=2), w, None, padding=1)
+    want, = torch.autograd.grad(y, a, gy)
+    assert torch.allclose(ga, want, rtol=1e-4, atol=1e-4)
+
+
 def test_conv_fwd_exact_integer_layout(K):
     """Asymmetric small-integer data: any A/B/C fragment transposition shows up as an exact mismatch."""
     B, Cin, Cout, H, W = 2, 8, 32, 32, 32
