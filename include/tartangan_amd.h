@@ -58,6 +58,20 @@ int tg_upconv3x3_fwd(const float* a, const float* wp, const float* bias /*nullab
 int tg_upconv3x3_weights_t(const float* w, float* w4t, int Cout, int Cin, void* stream);
 int tg_upconv3x3_dgrad_supported(int B, int Cin, int Cout, int H, int W);
 int tg_upconv3x3_dgrad(const float* gy, const float* w4t, float* ga, int B, int Cin, int Cout, int H, int W, void* stream);
+/* AvgPool2d(2)(conv3x3(x) + bias) [+ residual] as ONE 4x4-tap stride-2 convolution (discriminator.py:60-66: the second
+ * 3x3 conv of every discriminator block is followed by the block's average pool): 16 products per OUTPUT pixel and
+ * channel pair instead of 36, no full-resolution conv output, no pool pass.  The pair is 0.25 x the transpose of the
+ * up-conv above with the flipped, transposed filter, so the same two kernels serve with their roles swapped:
+ *   tg_poolconv3x3_weights  w [Cout][Cin][3][3] -> w4 [Cout][Cin][4][4] (forward) and wp [4][Cin][Cout][2][2] (dgrad)
+ *   tg_poolconv3x3_fwd      x (B,Cin,2H,2W), w4 -> y (B,Cout,H,W); bias / residual (shape of y) nullable
+ *   tg_poolconv3x3_dgrad    gy (B,Cout,H,W), wp -> gx (B,Cin,2H,2W)
+ * Supported where H x W >= 16 x 16 gives both kernels >= 256 workgroups (tg_poolconv3x3_supported); the weight
+ * gradient is tg_conv2d_wgrad(x, 0.25 * up2x(gy)).                                                          */
+int tg_poolconv3x3_weights(const float* w, float* w4, float* wp, int Cout, int Cin, void* stream);
+int tg_poolconv3x3_supported(int B, int Cin, int Cout, int H, int W);
+int tg_poolconv3x3_fwd(const float* x, const float* w4, const float* bias /*nullable*/, const float* residual /*nullable*/,
+                       float* y, int B, int Cin, int Cout, int H, int W, void* stream);
+int tg_poolconv3x3_dgrad(const float* gy, const float* wp, float* gx, int B, int Cin, int Cout, int H, int W, void* stream);
 /* gx = d/dx: correlation of gy with the transposed, spatially flipped filter
  * (what autograd's convolution_backward computes for grad_input)              */
 int tg_conv2d_dgrad(const float* gy, const float* w, float* gx,

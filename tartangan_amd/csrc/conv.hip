@@ -1060,8 +1060,9 @@ struct PatchStager2x {
 
 template <class G>
 __global__ void __launch_bounds__(CT_THREADS)
-conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, float* __restrict__ ga, Shape s /*Cin = gy channels,
-                Cout = ga channels, H x W = ga plane*/, int vec_x, int vec_w) {
+conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, const float* __restrict__ bias,
+                const float* __restrict__ residual, float* __restrict__ ga, Shape s /*Cin = gy channels, Cout = ga channels,
+                H x W = ga plane*/, int vec_x, int vec_w) {
   constexpr int CT = 16, NT = 4, KG = 4;
   using P = Patch2x<G>;
   using WT = WTile<4, CT, false>;                     // 16 taps per (out, in) channel pair
@@ -1110,7 +1111,46 @@ conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, flo
           acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[lane_b[n] + (g * KG) * P::CIS + (t >> 2) * P::PWS + (t & 3)], acc[0][n], 0, 0, 0);
       }
   }
-  Core::epilogue(acc, nullptr, nullptr, ga, s, tc, co0, pix0, j, h, wave);
+  Core::epilogue(acc, bias, residual, ga, s, tc, co0, pix0, j, h, wave);
+}
+
+// AvgPool2d(2) o conv3x3 = 0.25 * (transpose of the up-conv with the flipped, transposed filter): the same two kernels
+// with the roles swapped.  w4[co][ci][u][v] = 0.25 * sum_{kh in S'(u), kw in S'(v)} w[co][ci][kh][kw], S' = {0},{0,1},{1,2},{2};
+// its input gradient is the four-phase kernel with wp[dy][dx][ci][co][ty][tx], rows dy=0: {w2 | w1+w0}, dy=1: {w2+w1 | w0}, x 0.25.
+__global__ void __launch_bounds__(256) poolconv_weights_kernel(const float* __restrict__ w, float* __restrict__ w4, float* __restrict__ wp,
+                                                               int Cout, int Cin) {
+  const int e = blockIdx.x * 256 + threadIdx.x;          // e = co * Cin + ci
+  const int n = Cout * Cin;
+  if (e >= n) return;
+  const int co = e / Cin, ci = e - co * Cin;
+  float k[3][3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i / 3][i % 3] = 0.25f * w[(int64_t)e * 9 + i];
+  {
+    float r[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { r[0][c] = k[0][c]; r[1][c] = k[0][c] + k[1][c]; r[2][c] = k[1][c] + k[2][c]; r[3][c] = k[2][c]; }
+    float* o = w4 + (int64_t)e * 16;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { o[u * 4 + 0] = r[u][0]; o[u * 4 + 1] = r[u][0] + r[u][1]; o[u * 4 + 2] = r[u][1] + r[u][2]; o[u * 4 + 3] = r[u][2]; }
+  }
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      float r[2][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        r[0][c] = dy == 0 ? k[2][c] : k[2][c] + k[1][c];
+        r[1][c] = dy == 0 ? k[1][c] + k[0][c] : k[0][c];
+      }
+      float* o = wp + ((int64_t)(dy * 2 + dx) * n + (int64_t)ci * Cout + co) * 4;
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty) {
+        o[ty * 2 + 0] = dx == 0 ? r[ty][2] : r[ty][2] + r[ty][1];
+        o[ty * 2 + 1] = dx == 0 ? r[ty][1] + r[ty][0] : r[ty][0];
+      }
+    }
 }
 
 // =========================================================================== host dispatch
@@ -1306,8 +1346,50 @@ int tg_upconv3x3_dgrad(const float* gy, const float* w4t, float* ga, int B, int 
   dim3 grid(geo_tiles(g, B, H, W), (Cin + 15) / 16);
   const int vx = plane_vec_ok(gy, 2 * W), vw = tg_aligned16(w4t);
   hipStream_t st = tg_stream(stream);
-  if (g == GEO_16) conv_upT_kernel<G16><<<grid, CT_THREADS, 0, st>>>(gy, w4t, ga, s, vx, vw);
-  else conv_upT_kernel<GX><<<grid, CT_THREADS, 0, st>>>(gy, w4t, ga, s, vx, vw);
+  if (g == GEO_16) conv_upT_kernel<G16><<<grid, CT_THREADS, 0, st>>>(gy, w4t, nullptr, nullptr, ga, s, vx, vw);
+  else conv_upT_kernel<GX><<<grid, CT_THREADS, 0, st>>>(gy, w4t, nullptr, nullptr, ga, s, vx, vw);
+  return tg_launch_status();
+}
+
+int tg_poolconv3x3_weights(const float* w, float* w4, float* wp, int Cout, int Cin, void* stream) {
+  TG_CHECK_PTR(w); TG_CHECK_PTR(w4); TG_CHECK_PTR(wp); TG_CHECK_POS(Cout); TG_CHECK_POS(Cin);
+  poolconv_weights_kernel<<<(Cout * Cin + 255) / 256, 256, 0, tg_stream(stream)>>>(w, w4, wp, Cout, Cin);
+  return tg_launch_status();
+}
+
+int tg_poolconv3x3_supported(int B, int Cin, int Cout, int H, int W) {
+  const GeoId g = pick_geo(H, W);
+  if (!(g == GEO_16 || g == GEO_X) || check_shape(B, Cin, Cout, 2 * H, 2 * W, 3) != TG_OK) return 0;
+  const int64_t tiles = geo_tiles(g, B, H, W);
+  return tiles * ((Cout + 15) / 16) >= 256 && tiles * ((Cin + 15) / 16) >= 256;
+}
+
+int tg_poolconv3x3_fwd(const float* x, const float* w4, const float* bias, const float* residual, float* y, int B, int Cin, int Cout,
+                       int H, int W, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(w4); TG_CHECK_PTR(y);
+  if (!tg_poolconv3x3_supported(B, Cin, Cout, H, W)) return TG_EUNSUPPORTED;
+  Shape s{B, Cin, Cout, H, W};
+  const GeoId g = pick_geo(H, W);
+  dim3 grid(geo_tiles(g, B, H, W), (Cout + 15) / 16);
+  const int vx = plane_vec_ok(x, 2 * W), vw = tg_aligned16(w4);
+  hipStream_t st = tg_stream(stream);
+  if (g == GEO_16) conv_upT_kernel<G16><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, vx, vw);
+  else conv_upT_kernel<GX><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, vx, vw);
+  return tg_launch_status();
+}
+
+int tg_poolconv3x3_dgrad(const float* gy, const float* wp, float* gx, int B, int Cin, int Cout, int H, int W, void* stream) {
+  TG_CHECK_PTR(gy); TG_CHECK_PTR(wp); TG_CHECK_PTR(gx);
+  if (!tg_poolconv3x3_supported(B, Cin, Cout, H, W)) return TG_EUNSUPPORTED;
+  if (((uintptr_t)gx & 7) != 0) return TG_EUNSUPPORTED;
+  // the four-phase kernel with gy (Cout channels, H x W) as its low-resolution input and Cin output channels
+  Shape s{B, Cout, Cin, H, W};
+  const GeoId g = pick_geo(H, W);
+  dim3 grid(geo_tiles(g, B, H, W), (Cin + 15) / 16);
+  const int vx = plane_vec_ok(gy, W), vw = tg_aligned16(wp);
+  hipStream_t st = tg_stream(stream);
+  if (g == GEO_16) conv_upfwd_kernel<G16><<<grid, CT_THREADS, 0, st>>>(gy, wp, nullptr, nullptr, gx, s, vx, vw);
+  else conv_upfwd_kernel<GX><<<grid, CT_THREADS, 0, st>>>(gy, wp, nullptr, nullptr, gx, s, vx, vw);
   return tg_launch_status();
 }
 

@@ -334,6 +334,98 @@ def upconv3x3(a, weight, bias=None, residual=None):
     return _UpConv3x3.apply(a, weight, bias, residual)
 
 
+def _poolconv_weights(x_like, w):
+    Cout, Cin = w.shape[:2]
+    w4 = x_like.new_empty(Cout, Cin, 4, 4)
+    wp = x_like.new_empty(4, Cin, Cout, 2, 2)
+    K().poolconv3x3_weights(w.contiguous(), w4, wp, Cout, Cin)
+    return w4, wp
+
+
+class _PoolConv(Function):
+    """AvgPool2d(2)(conv3x3(x) + bias) [+ residual] as one 4x4-tap stride-2 convolution (tg_poolconv3x3_*).
+    Twice differentiable: its input gradient is ``_PoolConvT``, its weight gradient the ordinary 3x3 weight gradient of
+    (x, 0.25 * up2x(gy)) -- all Functions whose own backwards close the loop."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual=None):
+        x = x.contiguous()
+        B, Cin, H2, W2 = x.shape
+        Cout = w.shape[0]
+        w4, _ = _poolconv_weights(x, w)
+        if residual is not None:
+            residual = residual.contiguous()
+        y = x.new_empty(B, Cout, H2 // 2, W2 // 2)
+        K().poolconv3x3_fwd(x, w4, bias, residual, y, B, Cin, Cout, H2 // 2, W2 // 2)
+        ctx.save_for_backward(x, w, bias)
+        ctx.has_residual = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, bias = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        need_w = need[1] and _param_grads_wanted()
+        need_b = bias is not None and need[2] and _param_grads_wanted()
+        if need[0]:
+            gx = _PoolConvT.apply(gy, w)
+        if need_w or need_b:
+            sink_w, sink_b = _grad_sink(w), _grad_sink(bias)
+            if need_w:
+                gy_hi = _Up2x.apply(gy, 0.25)                       # what AvgPool2d's backward hands the conv
+                if sink_w is not None and (not need_b or sink_b is not None):
+                    _conv_wgrad_into(x, gy_hi, sink_w, None, 3, accumulate=1)
+                    if need_b:                                       # bias gradient at the LOW resolution
+                        Bn, Cn = gy.shape[:2]
+                        hw = gy[0, 0].numel()
+                        K().channel_sum(gy, sink_b, _ws(gy, K().bn_workspace(Bn, Cn, hw)), Bn, Cn, hw, 1)
+                    need_b = False
+                else:
+                    gw = _ConvWgrad.apply(x, gy_hi, 3)
+            if need_b:
+                gb = _ChannelSum.apply(gy)
+        return gx, gw, gb, (gy if ctx.has_residual and need[3] else None)
+
+
+class _PoolConvT(Function):
+    """transpose of ``_PoolConv`` in x: gy (B,Cout,H,W) -> gx (B,Cin,2H,2W) (the four-phase up-conv kernel)"""
+
+    @staticmethod
+    def forward(ctx, gy, w):
+        gy = gy.contiguous()
+        B, Cout, H, W = gy.shape
+        Cin = w.shape[1]
+        _, wp = _poolconv_weights(gy, w)
+        gx = gy.new_empty(B, Cin, 2 * H, 2 * W)
+        K().poolconv3x3_dgrad(gy, wp, gx, B, Cin, Cout, H, W)
+        ctx.save_for_backward(gy, w)
+        return gx
+
+    @staticmethod
+    def backward(ctx, v):
+        gy, w = ctx.saved_tensors
+        v = v.contiguous()
+        a_gy = a_w = None
+        if ctx.needs_input_grad[0]:
+            a_gy = _PoolConv.apply(v, w, None, None)
+        if ctx.needs_input_grad[1]:
+            a_w = _ConvWgrad.apply(v, _Up2x.apply(gy, 0.25), 3)
+        return a_gy, a_w
+
+
+def pool_conv3x3_supported(x, weight):
+    B, Cin, H2, W2 = x.shape
+    return (H2 % 2 == 0 and W2 % 2 == 0 and tuple(weight.shape[2:]) == (3, 3)
+            and bool(K().poolconv3x3_supported(B, Cin, weight.shape[0], H2 // 2, W2 // 2)))
+
+
+def pool_conv3x3(x, weight, bias=None, residual=None):
+    """F.avg_pool2d(F.conv2d(x, weight, bias, padding=1), 2) [+ residual]"""
+    return _PoolConv.apply(x, weight, bias, residual)
+
+
 class _Gemm(Function):
     """C = op(A) op(B); A,B 2-D or batched 3-D row-major."""
 

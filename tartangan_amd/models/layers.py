@@ -113,6 +113,13 @@ def run_layers(seq, x, residual=None):
             x = m.forward_act(x, mods[i + 1].negative_slope)
             i += 2
             continue
+        if (i == len(mods) - 2 and type(m) is Conv2d and type(mods[i + 1]) is AvgPool2d and m.kernel_size == (3, 3)
+                and x.dim() == 4 and TF.pool_conv3x3_supported(x, m.weight)):
+            # conv3x3 -> AvgPool2d(2) [+ shortcut]: one 4x4-tap stride-2 convolution (2.25x fewer FLOPs, no full-resolution
+            # conv output, no pool pass)
+            x, residual = TF.pool_conv3x3(x, m.weight, m.bias, residual), None
+            i += 2
+            continue
         if last and residual is not None and type(m) is Conv2d:
             x, residual = TF.conv2d(x, m.weight, m.bias, residual), None
         elif last and residual is not None and type(m) is AvgPool2d:

@@ -73,6 +73,32 @@ class Emulator:
         _v(ga, B, Cin, H, W).copy_(F.conv2d(_v(gy, B, Cout, 2 * H, 2 * W), _v(w4t, Cin, Cout, 4, 4), stride=2, padding=1))
         return 0
 
+    def poolconv3x3_weights(self, w, w4, wp, Cout, Cin):
+        k = _v(w, Cout, Cin, 3, 3) * 0.25
+        full = F.conv2d(F.pad(k.reshape(-1, 1, 3, 3), (1, 1, 1, 1)), torch.ones(1, 1, 2, 2))       # sum over (dy, dx)
+        _v(w4, Cout, Cin, 4, 4).copy_(full.view(Cout, Cin, 4, 4))
+        out = _v(wp, 4, Cin, Cout, 2, 2)
+        for dy in range(2):
+            rows = [k[:, :, 2], k[:, :, 1] + k[:, :, 0]] if dy == 0 else [k[:, :, 2] + k[:, :, 1], k[:, :, 0]]
+            for dx in range(2):
+                for ty in range(2):
+                    r = rows[ty]
+                    cols = [r[:, :, 2], r[:, :, 1] + r[:, :, 0]] if dx == 0 else [r[:, :, 2] + r[:, :, 1], r[:, :, 0]]
+                    out[dy * 2 + dx, :, :, ty, 0] = cols[0].t()
+                    out[dy * 2 + dx, :, :, ty, 1] = cols[1].t()
+        return 0
+
+    def poolconv3x3_supported(self, B, Cin, Cout, H, W):
+        return 1
+
+    def poolconv3x3_fwd(self, x, w4, bias, residual, y, B, Cin, Cout, H, W):
+        r = F.conv2d(_v(x, B, Cin, 2 * H, 2 * W), _v(w4, Cout, Cin, 4, 4), bias, stride=2, padding=1)
+        _v(y, B, Cout, H, W).copy_(r if residual is None else _v(residual, B, Cout, H, W) + r)
+        return 0
+
+    def poolconv3x3_dgrad(self, gy, wp, gx, B, Cin, Cout, H, W):
+        return self.upconv3x3_fwd(gy, wp, None, None, gx, B, Cout, Cin, H, W)
+
     def conv2d_dgrad(self, gy, w, gx, B, Cin, Cout, H, W, ks):
         gx.copy_(F.conv_transpose2d(_v(gy, B, Cout, H, W), _v(w, Cout, Cin, ks, ks), padding=ks // 2))
         return 0

@@ -113,6 +113,30 @@ def test_upconv3x3_dgrad(K, shape):
     assert torch.allclose(ga, want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('shape', [(16, 16, 16, 64, 64), (128, 32, 24, 16, 16), (20, 20, 18, 70, 50), (64, 64, 64, 16, 16), (8, 40, 33, 128, 32)])
+def test_poolconv3x3(K, shape):
+    """AvgPool2d(2) o conv3x3 as one stride-2 kernel, and its input gradient as the four-phase kernel."""
+    B, Cin, Cout, H, W = shape            # H x W = pooled output plane
+    assert K.poolconv3x3_supported(B, Cin, Cout, H, W)
+    x, w, b = rnd(B, Cin, 2 * H, 2 * W), rnd(Cout, Cin, 3, 3, scale=0.2), rnd(Cout)
+    w4, wp = torch.zeros(Cout, Cin, 4, 4), torch.zeros(4, Cin, Cout, 2, 2)
+    run_both(K, 'poolconv3x3_weights', [w, w4, wp, Cout, Cin], [1, 2], tol=1e-6)
+    E.poolconv3x3_weights(w, w4, wp, Cout, Cin)
+    y = torch.zeros(B, Cout, H, W)
+    run_both(K, 'poolconv3x3_fwd', [x, w4, b, None, y, B, Cin, Cout, H, W], [4], tol=5e-5)
+    run_both(K, 'poolconv3x3_fwd', [x, w4, None, rnd(B, Cout, H, W, seed=7), y, B, Cin, Cout, H, W], [4], tol=5e-5)
+    gy, gx = rnd(B, Cout, H, W, seed=3), torch.zeros(B, Cin, 2 * H, 2 * W)
+    run_both(K, 'poolconv3x3_dgrad', [gy, wp, gx, B, Cin, Cout, H, W], [2], tol=5e-5)
+    # and against the textbook formulation
+    E.poolconv3x3_fwd(x, w4, b, None, y, B, Cin, Cout, H, W)
+    E.poolconv3x3_dgrad(gy, wp, gx, B, Cin, Cout, H, W)
+    xr = x.clone().requires_grad_()
+    want = torch.nn.functional.avg_pool2d(torch.nn.functional.conv2d(xr, w, b, padding=1), 2)
+    assert torch.allclose(y, want, rtol=1e-4, atol=1e-4)
+    gwant, = torch.autograd.grad(want, xr, gy)
+    assert torch.allclose(gx, gwant, rtol=1e-4, atol=1e-4)
+
+
 def test_conv_fwd_exact_integer_layout(K):
     """Asymmetric small-integer data: any A/B/C fragment transposition shows up as an exact mismatch."""
     B, Cin, Cout, H, W = 2, 8, 32, 32, 32
