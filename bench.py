@@ -79,7 +79,8 @@ class KernelTimer:
                      'bilinear_half_fwd', 'bilinear_half_bwd', 'add', 'channel_sum', 'adam_step', 'ema', 'attn_fwd', 'attn_bwd', 'bn_train_fwd',
                      'maxpool2_fwd', 'maxpool2_bwd', 'scale_add_dev', 'dot', 'scale_dev', 'mul', 'lrelu_bwd', 'tanh_fwd', 'tanh_bwd',
                      'row_sum', 'row_bcast', 'bce_logits', 'sumsq', 'fill', 'scale', 'channel_bcast', 'conv2d_wgrad_partials',
-                     'conv2d_wgrad_reduce_batch', 'upconv3x3_fwd', 'upconv3x3_weights'):
+                     'conv2d_wgrad_reduce_batch', 'upconv3x3_fwd', 'upconv3x3_weights', 'upconv3x3_dgrad', 'upconv3x3_wgrad',
+                     'upconv3x3_weights_t', 'poolconv3x3_fwd', 'poolconv3x3_dgrad', 'poolconv3x3_wgrad', 'poolconv3x3_weights'):
             fn = getattr(self.K, name)
             self._saved[name] = fn
             setattr(self.K, name, self._wrap(name, fn))
@@ -127,8 +128,10 @@ class KernelTimer:
                 nbytes = 4.0 * (B * Cin * H * W + B * Cout * H * W + Cin * Cout * ks * ks)
                 if name == 'conv2d_fwd' and args[3] is not None:
                     nbytes += 4.0 * B * Cout * H * W          # fused residual read
-            if name == 'upconv3x3_fwd':           # (a, wp, bias, residual, y, B, Cin, Cout, H, W): 16 taps per source pixel
-                B, Cin, Cout, H, W = args[5:10]
+            STRIDE2 = {'upconv3x3_fwd': 5, 'poolconv3x3_fwd': 5, 'upconv3x3_dgrad': 3, 'poolconv3x3_dgrad': 3,
+                       'upconv3x3_wgrad': 5, 'poolconv3x3_wgrad': 5}
+            if name in STRIDE2:                   # (..., B, Cin, Cout, H, W, ...) with H x W the low-resolution plane: 16 taps
+                B, Cin, Cout, H, W = args[STRIDE2[name]:STRIDE2[name] + 5]
                 flops = 2.0 * B * Cin * Cout * H * W * 16
             d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             d['ms'] += ms

@@ -1114,6 +1114,103 @@ conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, con
   Core::epilogue(acc, bias, residual, ga, s, tc, co0, pix0, j, h, wave);
 }
 
+// The third member of the family: T[o][i][u][v] = sum_{b, r, c} lo[b][o][r][c] * hi[b][i][2r-1+u][2c-1+v], the product both
+// weight gradients reduce to (pooled conv: lo = gy, hi = x; up-conv: lo = a, hi = gy), 16 taps per low-resolution pixel and
+// channel pair instead of 36 for the 3x3 weight gradient on the (materialised) high-resolution pair.  Same scheme as
+// conv_wgrad_kernel: M = 16 `lo` channels, N = (8 `hi` channels x 16 taps) columns, K = pixels; per-workgroup partials.
+constexpr int S2_CKW = 8, S2_NT = S2_CKW * 16 / 16;
+template <class G>
+__global__ void __launch_bounds__(CT_THREADS)
+conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo, float* __restrict__ part, Shape s /*Cin = hi channels,
+                     Cout = lo channels, H x W = lo plane*/, int ntiles, int S, int vec_hi, int vec_lo) {
+  using P = Patch2x<G>;
+  constexpr int CKW = S2_CKW, NT = S2_NT, CT = 16;
+  constexpr int PATCH = CKW * P::CIS, GYT = CT * WG_GYS;
+  constexpr int RED = 4 * NT * 4 * 64;
+  constexpr int LDS_FLOATS = (PATCH + GYT) > RED ? (PATCH + GYT) : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  float* pl = lds;
+  float* gl = lds + PATCH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, h = lane >> 4;
+  const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CKW;
+  const int split = blockIdx.x;
+  int colbase[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) colbase[n] = n * P::CIS + (j >> 2) * P::PWS + (j & 3);      // column n*16 + j = (hi channel n, tap j)
+  constexpr int RPW = 64 / G::TW;                                    // tile rows per wave
+  const int lane_b = (2 * wave * RPW) * P::PWS + 2 * h + P::ORG;
+  const int lane_a = j * WG_GYS + wave * 64 + h;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  PatchStager2x<G, CKW> ps;
+  GyStager<G, CT> gs;
+  const int H2 = 2 * s.H, W2 = 2 * s.W;
+  if (split < ntiles) {
+    const TileCoord tc = decode_tile<G>(split, s.H, s.W);
+    ps.load(hi, s.B, s.Cin, H2, W2, ci0, tc, vec_hi);
+    gs.load(lo, s, co0, tc, vec_lo);
+  }
+  for (int t = split; t < ntiles; t += S) {
+    __syncthreads();
+    ps.store(pl);
+    gs.store(gl);
+    __syncthreads();
+    if (t + S < ntiles) {
+      const TileCoord tn = decode_tile<G>(t + S, s.H, s.W);
+      ps.load(hi, s.B, s.Cin, H2, W2, ci0, tn, vec_hi);
+      gs.load(lo, s, co0, tn, vec_lo);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int pg = 4 * g;
+      const int goff = 2 * (pg / G::TW) * P::PWS + 2 * (pg % G::TW);
+      const float a = gl[lane_a + 4 * g];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[colbase[n] + lane_b + goff], acc[n], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* red = lds;
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave * NT + n) * 4 + r) * 64 + lane] = acc[n][r];
+  __syncthreads();
+  constexpr int PER_WAVE = NT * 4 * 64;
+  for (int e = threadIdx.x; e < PER_WAVE; e += CT_THREADS) {
+    const float v = (red[e] + red[PER_WAVE + e]) + (red[2 * PER_WAVE + e] + red[3 * PER_WAVE + e]);
+    const int l = e & 63, q = e >> 6;
+    const int r = q & 3, n = q >> 2;
+    const int co = co0 + (l >> 4) * 4 + r, ci = ci0 + n, tap = l & 15;
+    if (co < s.Cout && ci < s.Cin) part[(((int64_t)split * s.Cout + co) * s.Cin + ci) * 16 + tap] = v;
+  }
+}
+
+// T -> 3x3 weight gradient.  mode 0 (pooled conv, T[co][ci]):  gw[kh][kw] (+)= 0.25 sum_{dy,dx} T[dy+kh][dx+kw];
+// mode 1 (up-conv, T[ci][co]): gw[kh][kw] (+)= sum_{u: kh in S(u)} sum_{v: kw in S(v)} T[u][v], S = {2},{1,2},{0,1},{0}.
+__global__ void __launch_bounds__(256) s2wgrad_fold_kernel(const float* __restrict__ T, float* __restrict__ gw, int Cout, int Cin, int mode,
+                                                           int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;          // e = co * Cin + ci
+  if (e >= Cout * Cin) return;
+  const int co = e / Cin, ci = e - co * Cin;
+  const float* t = T + (mode == 0 ? (int64_t)e : (int64_t)ci * Cout + co) * 16;
+  float k[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) k[i >> 2][i & 3] = t[i];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int u0 = mode == 0 ? kh : 2 - kh, v0 = mode == 0 ? kw : 2 - kw;      // rows u0, u0 + 1 and columns v0, v0 + 1
+      float r = (k[u0][v0] + k[u0][v0 + 1]) + (k[u0 + 1][v0] + k[u0 + 1][v0 + 1]);
+      if (mode == 0) r *= 0.25f;
+      float* o = gw + (int64_t)e * 9 + kh * 3 + kw;
+      *o = accumulate ? *o + r : r;
+    }
+}
+
 // AvgPool2d(2) o conv3x3 = 0.25 * (transpose of the up-conv with the flipped, transposed filter): the same two kernels
 // with the roles swapped.  w4[co][ci][u][v] = 0.25 * sum_{kh in S'(u), kw in S'(v)} w[co][ci][kh][kw], S' = {0},{0,1},{1,2},{2};
 // its input gradient is the four-phase kernel with wp[dy][dx][ci][co][ty][tx], rows dy=0: {w2 | w1+w0}, dy=1: {w2+w1 | w0}, x 0.25.
@@ -1349,6 +1446,58 @@ int tg_upconv3x3_dgrad(const float* gy, const float* w4t, float* ga, int B, int 
   if (g == GEO_16) conv_upT_kernel<G16><<<grid, CT_THREADS, 0, st>>>(gy, w4t, nullptr, nullptr, ga, s, vx, vw);
   else conv_upT_kernel<GX><<<grid, CT_THREADS, 0, st>>>(gy, w4t, nullptr, nullptr, ga, s, vx, vw);
   return tg_launch_status();
+}
+
+static inline int s2_splits(int tiles, int lo_tiles, int hi_chunks) {
+  int S = 768 / (lo_tiles * hi_chunks);
+  const int smax = tiles >= 4096 ? 512 : 256;
+  if (S > smax) S = smax;
+  if (S < 1) S = 1;
+  if (S > tiles) S = tiles;
+  return S;
+}
+// workspace: S partials of T plus T itself
+static size_t s2_workspace(int B, int Clo, int Chi, int H, int W) {
+  const GeoId g = pick_geo(H, W);
+  const int S = s2_splits(geo_tiles(g, B, H, W), (Clo + 15) / 16, (Chi + S2_CKW - 1) / S2_CKW);
+  return ((size_t)S + 1) * Clo * Chi * 16 * sizeof(float);
+}
+static int s2_wgrad(const float* hi, const float* lo, float* gw, float* ws, size_t ws_bytes, int B, int Clo, int Chi, int H, int W,
+                    int Cout, int Cin, int mode, int accumulate, hipStream_t st) {
+  const GeoId g = pick_geo(H, W);
+  if (!(g == GEO_16 || g == GEO_X) || check_shape(B, Clo, Chi, 2 * H, 2 * W, 3) != TG_OK) return TG_EUNSUPPORTED;
+  if (ws_bytes < s2_workspace(B, Clo, Chi, H, W)) return TG_EWORKSPACE;
+  const int tiles = geo_tiles(g, B, H, W), lo_tiles = (Clo + 15) / 16, hi_chunks = (Chi + S2_CKW - 1) / S2_CKW;
+  const int S = s2_splits(tiles, lo_tiles, hi_chunks);
+  Shape s{B, Chi, Clo, H, W};
+  dim3 grid(S, lo_tiles, hi_chunks);
+  const int vh = plane_vec_ok(hi, 2 * W), vl = plane_vec_ok(lo, W);
+  if (g == GEO_16) conv_wgrad_s2_kernel<G16><<<grid, CT_THREADS, 0, st>>>(hi, lo, ws, s, tiles, S, vh, vl);
+  else conv_wgrad_s2_kernel<GX><<<grid, CT_THREADS, 0, st>>>(hi, lo, ws, s, tiles, S, vh, vl);
+  const int64_t E = (int64_t)Clo * Chi * 16;
+  float* T = ws + (size_t)S * E;
+  wgrad_reduce_kernel<<<(int)((E + 63) / 64), 256, 0, st>>>(ws, T, E, S, nullptr, nullptr, 0, 0);
+  s2wgrad_fold_kernel<<<(Cout * Cin + 255) / 256, 256, 0, st>>>(T, gw, Cout, Cin, mode, accumulate);
+  return tg_launch_status();
+}
+
+size_t tg_poolconv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  return s2_workspace(B, Cout, Cin, H, W);
+}
+int tg_poolconv3x3_wgrad(const float* x, const float* gy, float* gw, float* workspace, size_t workspace_bytes, int B, int Cin,
+                         int Cout, int H, int W, int accumulate, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(gy); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
+  return s2_wgrad(x, gy, gw, workspace, workspace_bytes, B, Cout, Cin, H, W, Cout, Cin, 0, accumulate, tg_stream(stream));
+}
+size_t tg_upconv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  return s2_workspace(B, Cin, Cout, H, W);
+}
+int tg_upconv3x3_wgrad(const float* a, const float* gy, float* gw, float* workspace, size_t workspace_bytes, int B, int Cin,
+                       int Cout, int H, int W, int accumulate, void* stream) {
+  TG_CHECK_PTR(a); TG_CHECK_PTR(gy); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
+  return s2_wgrad(gy, a, gw, workspace, workspace_bytes, B, Cin, Cout, H, W, Cout, Cin, 1, accumulate, tg_stream(stream));
 }
 
 int tg_poolconv3x3_weights(const float* w, float* w4, float* wp, int Cout, int Cin, void* stream) {

@@ -305,17 +305,28 @@ class _UpConv3x3(Function):
                 ga = _Pool2.apply(_ConvDgrad.apply(gy, w), 1.0)
         need_w = need[1] and _param_grads_wanted()
         need_b = bias is not None and need[2] and _param_grads_wanted()
+        sink_w, sink_b = _grad_sink(w), _grad_sink(bias)
         if need_w:
-            au = upsample_nearest2x(a)
-            sink_w, sink_b = _grad_sink(w), _grad_sink(bias)
-            if sink_w is not None and (not need_b or sink_b is not None):
-                _conv_wgrad_into(au, gy, sink_w, sink_b if need_b else None, 3, accumulate=1)
+            B, Cin, H, W = a.shape
+            Cout = w.shape[0]
+            if K().upconv3x3_dgrad_supported(B, Cin, Cout, H, W):
+                # 16-tap stride-2 weight gradient on (a, gy): no up2x(a), 2.25x fewer FLOPs
+                ws = _ws(a, K().upconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
+                if sink_w is None:
+                    gw = torch.empty_like(w)
+                K().upconv3x3_wgrad(a, gy, gw if sink_w is None else sink_w, ws, ws.numel() * 4, B, Cin, Cout, H, W,
+                                    0 if sink_w is None else 1)
+            elif sink_w is not None:
+                _conv_wgrad_into(upsample_nearest2x(a), gy, sink_w, None, 3, accumulate=1)
             else:
-                gw = _ConvWgrad.apply(au, gy, 3)
-                if need_b:
-                    gb = _ChannelSum.apply(gy)
-        elif need_b:
-            gb = _ChannelSum.apply(gy)
+                gw = _ConvWgrad.apply(upsample_nearest2x(a), gy, 3)
+        if need_b:
+            if sink_b is not None:
+                Bn, Cn = gy.shape[:2]
+                hw = gy[0, 0].numel()
+                K().channel_sum(gy, sink_b, _ws(gy, K().bn_workspace(Bn, Cn, hw)), Bn, Cn, hw, 1)
+            else:
+                gb = _ChannelSum.apply(gy)
         return ga, gw, gb, gres
 
 
@@ -371,20 +382,25 @@ class _PoolConv(Function):
         need_b = bias is not None and need[2] and _param_grads_wanted()
         if need[0]:
             gx = _PoolConvT.apply(gy, w)
-        if need_w or need_b:
-            sink_w, sink_b = _grad_sink(w), _grad_sink(bias)
-            if need_w:
-                gy_hi = _Up2x.apply(gy, 0.25)                       # what AvgPool2d's backward hands the conv
-                if sink_w is not None and (not need_b or sink_b is not None):
-                    _conv_wgrad_into(x, gy_hi, sink_w, None, 3, accumulate=1)
-                    if need_b:                                       # bias gradient at the LOW resolution
-                        Bn, Cn = gy.shape[:2]
-                        hw = gy[0, 0].numel()
-                        K().channel_sum(gy, sink_b, _ws(gy, K().bn_workspace(Bn, Cn, hw)), Bn, Cn, hw, 1)
-                    need_b = False
-                else:
-                    gw = _ConvWgrad.apply(x, gy_hi, 3)
-            if need_b:
+        if need_w:
+            if torch.is_grad_enabled():
+                gw = _ConvWgrad.apply(x, _Up2x.apply(gy, 0.25), 3)  # differentiable form (what AvgPool2d's backward hands the conv)
+            else:
+                B, Cin, H2, W2 = x.shape
+                Cout = w.shape[0]
+                sink_w = _grad_sink(w)
+                ws = _ws(x, K().poolconv3x3_wgrad_workspace(B, Cin, Cout, H2 // 2, W2 // 2))
+                if sink_w is None:
+                    gw = torch.empty_like(w)
+                K().poolconv3x3_wgrad(x, gy, gw if sink_w is None else sink_w, ws, ws.numel() * 4, B, Cin, Cout, H2 // 2, W2 // 2,
+                                      0 if sink_w is None else 1)
+        if need_b:                                                   # bias gradient at the LOW resolution
+            sink_b = _grad_sink(bias)
+            if sink_b is not None:
+                Bn, Cn = gy.shape[:2]
+                hw = gy[0, 0].numel()
+                K().channel_sum(gy, sink_b, _ws(gy, K().bn_workspace(Bn, Cn, hw)), Bn, Cn, hw, 1)
+            else:
                 gb = _ChannelSum.apply(gy)
         return gx, gw, gb, (gy if ctx.has_residual and need[3] else None)
 

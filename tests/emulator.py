@@ -99,6 +99,24 @@ class Emulator:
     def poolconv3x3_dgrad(self, gy, wp, gx, B, Cin, Cout, H, W):
         return self.upconv3x3_fwd(gy, wp, None, None, gx, B, Cout, Cin, H, W)
 
+    def poolconv3x3_wgrad_workspace(self, B, Cin, Cout, H, W):
+        return 16
+
+    def poolconv3x3_wgrad(self, x, gy, gw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate):
+        g_hi = (_v(gy, B, Cout, H, W) * 0.25).repeat_interleave(2, 2).repeat_interleave(2, 3)
+        r = torch.nn.grad.conv2d_weight(_v(x, B, Cin, 2 * H, 2 * W), (Cout, Cin, 3, 3), g_hi, padding=1)
+        gw.copy_(gw + r if accumulate else r)
+        return 0
+
+    def upconv3x3_wgrad_workspace(self, B, Cin, Cout, H, W):
+        return 16
+
+    def upconv3x3_wgrad(self, a, gy, gw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate):
+        a_hi = _v(a, B, Cin, H, W).repeat_interleave(2, 2).repeat_interleave(2, 3)
+        r = torch.nn.grad.conv2d_weight(a_hi, (Cout, Cin, 3, 3), _v(gy, B, Cout, 2 * H, 2 * W), padding=1)
+        gw.copy_(gw + r if accumulate else r)
+        return 0
+
     def conv2d_dgrad(self, gy, w, gx, B, Cin, Cout, H, W, ks):
         gx.copy_(F.conv_transpose2d(_v(gy, B, Cout, H, W), _v(w, Cout, Cin, ks, ks), padding=ks // 2))
         return 0

@@ -137,6 +137,24 @@ def test_poolconv3x3(K, shape):
     assert torch.allclose(gx, gwant, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('shape', [(16, 16, 16, 64, 64), (32, 32, 24, 16, 16), (10, 20, 18, 70, 50), (64, 64, 64, 16, 16), (4, 40, 33, 64, 32)])
+def test_stride2_weight_gradients(K, shape):
+    """16-tap stride-2 weight gradients of the pooled conv and of the up-conv == the 3x3 weight gradient on the
+    materialised high-resolution pair."""
+    B, Cin, Cout, H, W = shape
+    w0 = rnd(Cout, Cin, 3, 3, seed=9)
+    # pooled conv: x high resolution (Cin), gy low resolution (Cout)
+    x, gy = rnd(B, Cin, 2 * H, 2 * W), rnd(B, Cout, H, W, seed=3)
+    ws = workspace(K.poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
+    for acc in (0, 1):
+        run_both(K, 'poolconv3x3_wgrad', [x, gy, w0.clone(), ws, ws.numel() * 4, B, Cin, Cout, H, W, acc], [2], tol=1e-4, scratch=[3])
+    # up-conv: a low resolution (Cin), gy high resolution (Cout)
+    a, gyh = rnd(B, Cin, H, W, seed=4), rnd(B, Cout, 2 * H, 2 * W, seed=5)
+    ws = workspace(K.upconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
+    for acc in (0, 1):
+        run_both(K, 'upconv3x3_wgrad', [a, gyh, w0.clone(), ws, ws.numel() * 4, B, Cin, Cout, H, W, acc], [2], tol=1e-4, scratch=[3])
+
+
 def test_conv_fwd_exact_integer_layout(K):
     """Asymmetric small-integer data: any A/B/C fragment transposition shows up as an exact mismatch."""
     B, Cin, Cout, H, W = 2, 8, 32, 32, 32
