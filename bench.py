@@ -133,6 +133,8 @@ class KernelTimer:
             if name in STRIDE2:                   # (..., B, Cin, Cout, H, W, ...) with H x W the low-resolution plane: 16 taps
                 B, Cin, Cout, H, W = args[STRIDE2[name]:STRIDE2[name] + 5]
                 flops = 2.0 * B * Cin * Cout * H * W * 16
+                hi = Cin if name.startswith('poolconv') else Cout      # channels of the high-resolution (2H x 2W) tensor
+                nbytes = 4.0 * (B * hi * 4 * H * W + B * (Cin + Cout - hi) * H * W + Cin * Cout * 16)
             d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             d['ms'] += ms
             d['launches'] += 1
@@ -156,11 +158,19 @@ def hbm_traffic_per_launch(a, agg):
         return None
     with open(path) as f:
         k = json.load(f)['kernels']
-    f_, d_ = k.get('conv_fwd_kernel (fwd)'), k.get('conv_fwd_kernel (dgrad)')
-    if not f_ or not d_:
-        return None
-    nf, nd = agg['conv2d_fwd']['launches'], agg['conv2d_dgrad']['launches']
-    return round((nf * f_['hbm_bytes_per_launch'] + nd * d_['hbm_bytes_per_launch']) / (nf + nd))
+    tot = n = 0
+    for name, kernel in CONV_FAMILY.items():
+        if name in agg and kernel in k:
+            tot += agg[name]['launches'] * k[kernel]['hbm_bytes_per_launch']
+            n += agg[name]['launches']
+    return round(tot / n) if n else None
+
+
+# the MFMA convolution kernels that produce activations / activation gradients: C-ABI entry point -> kernel name in the
+# PMC summary.  (The stride-2 kernels serve the generator's up-convs and the discriminator's pooled convs.)
+CONV_FAMILY = {'conv2d_fwd': 'conv_fwd_kernel (fwd)', 'conv2d_dgrad': 'conv_fwd_kernel (dgrad)',
+               'upconv3x3_fwd': 'conv_upfwd_kernel', 'poolconv3x3_dgrad': 'conv_upfwd_kernel',
+               'upconv3x3_dgrad': 'conv_upT_kernel', 'poolconv3x3_fwd': 'conv_upT_kernel'}
 
 
 def cpu_baseline(config, kind, batch):
@@ -266,9 +276,9 @@ def main():
             agg = kt.summary() if world == 1 else {}
             tr._graphs, tr._graph_requested, tr.rng_feed.mode = saved
             if agg:
-                conv = {k: agg['conv2d_fwd'][k] + agg['conv2d_dgrad'][k] for k in ('ms', 'launches', 'flops', 'bytes')}
+                conv = {k: sum(agg[n][k] for n in CONV_FAMILY if n in agg) for k in ('ms', 'launches', 'flops', 'bytes')}
                 ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
-                out['roofline'] = {'bound': 'mfma', 'kernel': 'conv_fwd_kernel (MFMA implicit-GEMM conv, fwd + dgrad launches)',
+                out['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA implicit-GEMM conv family: conv_fwd_kernel (fwd + dgrad), conv_upfwd_kernel, conv_upT_kernel',
                                    'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                    'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                                    'traffic': hbm_traffic_per_launch(a, agg),
