@@ -975,20 +975,27 @@ __global__ void __launch_bounds__(256) upconvT_weights_kernel(const float* __res
 }
 
 template <class G>
-struct Patch2x {                       // high-resolution window of a low-resolution tile
+struct Patch2x {                       // high-resolution windows of a low-resolution tile (one per image of the tile)
   static constexpr int PH = 2 * G::TH + 2, TW2 = 2 * G::TW;
   static constexpr int IOFF = 4, ORG = IOFF - 1;
   static constexpr int PWS = TW2 + 2 * IOFF;
-  static constexpr int RAW = PH * PWS;
+  static constexpr int IMG = PH * PWS;
+  static constexpr int RAW = G::NI * IMG;
   static constexpr int CIS = ((RAW + 31) / 32) * 32 + 16;
-  static_assert(G::NI == 1, "single-image tiles");
+  static constexpr int PPI = G::TH * G::TW;            // low-resolution pixels per image
+  static_assert(PPI % 64 == 0, "a wave's 64 pixels stay inside one image");
+  // LDS offset (inside one channel) of the top-left tap of low-resolution pixel p
+  __device__ __forceinline__ static int pix(int p) {
+    const int img = p / PPI, rem = p % PPI;
+    return img * IMG + 2 * (rem / G::TW) * PWS + 2 * (rem % G::TW) + ORG;
+  }
 };
 
 template <class G, int CK>
 struct PatchStager2x {
   using P = Patch2x<G>;
   static constexpr int Q = P::TW2 / 4;
-  static constexpr int ROWS = CK * P::PH;
+  static constexpr int ROWS = CK * G::NI * P::PH;
   static constexpr int NV = (ROWS * Q + CT_THREADS - 1) / CT_THREADS;
   static constexpr int NHALO = ROWS * 2;
   static constexpr int NH = (NHALO + CT_THREADS - 1) / CT_THREADS;
@@ -1004,10 +1011,11 @@ struct PatchStager2x {
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       if (e < ROWS * Q) {
         const int q = e % Q, row = e / Q;
-        const int r = row % P::PH, ci = row / P::PH;
+        const int r = row % P::PH, t = row / P::PH;
+        const int img = t % G::NI, ci = t / G::NI;
         const int hh = 2 * tc.h0 - 1 + r, ww = 2 * tc.w0 + 4 * q;
-        const uint32_t off = (__umul24(ci, HW2) + __umul24(r, W2) + 1 + 4 * q) << 2;
-        if (c0 + ci < C && hh >= 0 && hh < H2 && ww < W2) {
+        const uint32_t off = (__umul24(__umul24(img, C) + ci, HW2) + __umul24(r, W2) + 1 + 4 * q) << 2;
+        if (tc.b0 + img < B && c0 + ci < C && hh >= 0 && hh < H2 && ww < W2) {
           const char* p = base + off;
           if (vec) {
             val = *reinterpret_cast<const float4*>(p);
@@ -1027,11 +1035,12 @@ struct PatchStager2x {
       float val = 0.f;
       if (e < NHALO) {
         const int row = e >> 1;
-        const int r = row % P::PH, ci = row / P::PH;
+        const int r = row % P::PH, t = row / P::PH;
+        const int img = t % G::NI, ci = t / G::NI;
         const int hh = 2 * tc.h0 - 1 + r;
         const int ww = (e & 1) ? 2 * tc.w0 + P::TW2 : 2 * tc.w0 - 1;
-        if (c0 + ci < C && hh >= 0 && hh < H2 && ww >= 0 && ww < W2)
-          val = *reinterpret_cast<const float*>(base + ((__umul24(ci, HW2) + __umul24(r, W2) + ((e & 1) ? P::TW2 + 1 : 0)) << 2));
+        if (tc.b0 + img < B && c0 + ci < C && hh >= 0 && hh < H2 && ww >= 0 && ww < W2)
+          val = *reinterpret_cast<const float*>(base + ((__umul24(__umul24(img, C) + ci, HW2) + __umul24(r, W2) + ((e & 1) ? P::TW2 + 1 : 0)) << 2));
       }
       hv[i] = val;
     }
@@ -1042,8 +1051,9 @@ struct PatchStager2x {
       const int e = threadIdx.x + i * CT_THREADS;
       if (e < ROWS * Q) {
         const int q = e % Q, row = e / Q;
-        const int r = row % P::PH, ci = row / P::PH;
-        *reinterpret_cast<float4*>(lds + ci * P::CIS + r * P::PWS + P::IOFF + 4 * q) = v[i];
+        const int r = row % P::PH, t = row / P::PH;
+        const int img = t % G::NI, ci = t / G::NI;
+        *reinterpret_cast<float4*>(lds + ci * P::CIS + img * P::IMG + r * P::PWS + P::IOFF + 4 * q) = v[i];
       }
     }
 #pragma unroll
@@ -1051,8 +1061,9 @@ struct PatchStager2x {
       const int e = threadIdx.x + i * CT_THREADS;
       if (e < NHALO) {
         const int row = e >> 1;
-        const int r = row % P::PH, ci = row / P::PH;
-        lds[ci * P::CIS + r * P::PWS + ((e & 1) ? P::IOFF + P::TW2 : P::IOFF - 1)] = hv[i];
+        const int r = row % P::PH, t = row / P::PH;
+        const int img = t % G::NI, ci = t / G::NI;
+        lds[ci * P::CIS + img * P::IMG + r * P::PWS + ((e & 1) ? P::IOFF + P::TW2 : P::IOFF - 1)] = hv[i];
       }
     }
   }
@@ -1079,8 +1090,7 @@ conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, con
   int lane_b[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int p = pix0 + n * 16 + j;
-    lane_b[n] = h * P::CIS + (2 * (p / G::TW)) * P::PWS + 2 * (p % G::TW) + P::ORG;
+    lane_b[n] = h * P::CIS + P::pix(pix0 + n * 16 + j);
   }
   const int lane_a = (h * KK) * CTS + j;
   using Core = FwdCore<G, 3, 16, 1, false>;
@@ -1138,8 +1148,7 @@ conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo,
   int colbase[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) colbase[n] = n * P::CIS + (j >> 2) * P::PWS + (j & 3);      // column n*16 + j = (hi channel n, tap j)
-  constexpr int RPW = 64 / G::TW;                                    // tile rows per wave
-  const int lane_b = (2 * wave * RPW) * P::PWS + 2 * h + P::ORG;
+  const int lane_b = P::pix(wave * 64) + 2 * h;                     // the wave's first pixel (its 64 pixels share an image)
   const int lane_a = j * WG_GYS + wave * 64 + h;
   f32x4 acc[NT];
 #pragma unroll
@@ -1269,6 +1278,15 @@ static inline int geo_tiles(GeoId g, int B, int H, int W) {
 
 // 16-byte row loads need W % 4 == 0 and a 16-byte aligned base
 static inline int plane_vec_ok(const void* p, int W) { return (W % 4 == 0) && tg_aligned16(p); }
+// stride-2 family: low-resolution planes of 8x8 (4 images per tile), 16x16 and larger; workgroups needed to pay off
+static inline bool s2_geo(GeoId g) { return g == GEO_8 || g == GEO_16 || g == GEO_X; }
+static inline int64_t s2_min_wgs(GeoId g) { return g == GEO_8 ? 128 : 256; }
+#define TG_S2_DISPATCH(g, KERNEL, ...)                                                   \
+  do {                                                                                   \
+    if ((g) == GEO_8) KERNEL<G8><<<grid, CT_THREADS, 0, st>>>(__VA_ARGS__);              \
+    else if ((g) == GEO_16) KERNEL<G16><<<grid, CT_THREADS, 0, st>>>(__VA_ARGS__);       \
+    else KERNEL<GX><<<grid, CT_THREADS, 0, st>>>(__VA_ARGS__);                           \
+  } while (0)
 
 template <class G, int KS, bool DGRAD>
 int launch_fwd_geo(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
@@ -1404,11 +1422,10 @@ int tg_upconv3x3_fwd(const float* a, const float* wp, const float* bias, const f
     const GeoId g = pick_geo(H, W);
     const int cot = (Cout + 15) / 16;
     const bool aligned8 = (((uintptr_t)y & 7) == 0) && (!residual || ((uintptr_t)residual & 7) == 0);
-    if ((g == GEO_16 || g == GEO_X) && aligned8 && (int64_t)geo_tiles(g, B, H, W) * cot >= 256) {
+    if (s2_geo(g) && aligned8 && (int64_t)geo_tiles(g, B, H, W) * cot >= s2_min_wgs(g)) {
       const int vx = plane_vec_ok(a, W), vw = tg_aligned16(wp);
       dim3 grid(geo_tiles(g, B, H, W), cot);
-      if (g == GEO_16) conv_upfwd_kernel<G16><<<grid, CT_THREADS, 0, st>>>(a, wp, bias, residual, y, s, vx, vw);
-      else conv_upfwd_kernel<GX><<<grid, CT_THREADS, 0, st>>>(a, wp, bias, residual, y, s, vx, vw);
+      TG_S2_DISPATCH(g, conv_upfwd_kernel, a, wp, bias, residual, y, s, vx, vw);
       return tg_launch_status();
     }
   }
@@ -1430,8 +1447,8 @@ int tg_upconv3x3_weights_t(const float* w, float* w4t, int Cout, int Cin, void* 
 
 int tg_upconv3x3_dgrad_supported(int B, int Cin, int Cout, int H, int W) {
   const GeoId g = pick_geo(H, W);
-  return (g == GEO_16 || g == GEO_X) && check_shape(B, Cin, Cout, 2 * H, 2 * W, 3) == TG_OK &&
-         (int64_t)geo_tiles(g, B, H, W) * ((Cin + 15) / 16) >= 256;
+  return s2_geo(g) && check_shape(B, Cin, Cout, 2 * H, 2 * W, 3) == TG_OK &&
+         (int64_t)geo_tiles(g, B, H, W) * ((Cin + 15) / 16) >= s2_min_wgs(g);
 }
 
 int tg_upconv3x3_dgrad(const float* gy, const float* w4t, float* ga, int B, int Cin, int Cout, int H, int W, void* stream) {
@@ -1443,8 +1460,7 @@ int tg_upconv3x3_dgrad(const float* gy, const float* w4t, float* ga, int B, int 
   dim3 grid(geo_tiles(g, B, H, W), (Cin + 15) / 16);
   const int vx = plane_vec_ok(gy, 2 * W), vw = tg_aligned16(w4t);
   hipStream_t st = tg_stream(stream);
-  if (g == GEO_16) conv_upT_kernel<G16><<<grid, CT_THREADS, 0, st>>>(gy, w4t, nullptr, nullptr, ga, s, vx, vw);
-  else conv_upT_kernel<GX><<<grid, CT_THREADS, 0, st>>>(gy, w4t, nullptr, nullptr, ga, s, vx, vw);
+  TG_S2_DISPATCH(g, conv_upT_kernel, gy, w4t, nullptr, nullptr, ga, s, vx, vw);
   return tg_launch_status();
 }
 
@@ -1465,15 +1481,14 @@ static size_t s2_workspace(int B, int Clo, int Chi, int H, int W) {
 static int s2_wgrad(const float* hi, const float* lo, float* gw, float* ws, size_t ws_bytes, int B, int Clo, int Chi, int H, int W,
                     int Cout, int Cin, int mode, int accumulate, hipStream_t st) {
   const GeoId g = pick_geo(H, W);
-  if (!(g == GEO_16 || g == GEO_X) || check_shape(B, Clo, Chi, 2 * H, 2 * W, 3) != TG_OK) return TG_EUNSUPPORTED;
+  if (!s2_geo(g) || check_shape(B, Clo, Chi, 2 * H, 2 * W, 3) != TG_OK) return TG_EUNSUPPORTED;
   if (ws_bytes < s2_workspace(B, Clo, Chi, H, W)) return TG_EWORKSPACE;
   const int tiles = geo_tiles(g, B, H, W), lo_tiles = (Clo + 15) / 16, hi_chunks = (Chi + S2_CKW - 1) / S2_CKW;
   const int S = s2_splits(tiles, lo_tiles, hi_chunks);
   Shape s{B, Chi, Clo, H, W};
   dim3 grid(S, lo_tiles, hi_chunks);
   const int vh = plane_vec_ok(hi, 2 * W), vl = plane_vec_ok(lo, W);
-  if (g == GEO_16) conv_wgrad_s2_kernel<G16><<<grid, CT_THREADS, 0, st>>>(hi, lo, ws, s, tiles, S, vh, vl);
-  else conv_wgrad_s2_kernel<GX><<<grid, CT_THREADS, 0, st>>>(hi, lo, ws, s, tiles, S, vh, vl);
+  TG_S2_DISPATCH(g, conv_wgrad_s2_kernel, hi, lo, ws, s, tiles, S, vh, vl);
   const int64_t E = (int64_t)Clo * Chi * 16;
   float* T = ws + (size_t)S * E;
   wgrad_reduce_kernel<<<(int)((E + 63) / 64), 256, 0, st>>>(ws, T, E, S, nullptr, nullptr, 0, 0);
@@ -1508,9 +1523,9 @@ int tg_poolconv3x3_weights(const float* w, float* w4, float* wp, int Cout, int C
 
 int tg_poolconv3x3_supported(int B, int Cin, int Cout, int H, int W) {
   const GeoId g = pick_geo(H, W);
-  if (!(g == GEO_16 || g == GEO_X) || check_shape(B, Cin, Cout, 2 * H, 2 * W, 3) != TG_OK) return 0;
+  if (!s2_geo(g) || check_shape(B, Cin, Cout, 2 * H, 2 * W, 3) != TG_OK) return 0;
   const int64_t tiles = geo_tiles(g, B, H, W);
-  return tiles * ((Cout + 15) / 16) >= 256 && tiles * ((Cin + 15) / 16) >= 256;
+  return tiles * ((Cout + 15) / 16) >= s2_min_wgs(g) && tiles * ((Cin + 15) / 16) >= s2_min_wgs(g);
 }
 
 int tg_poolconv3x3_fwd(const float* x, const float* w4, const float* bias, const float* residual, float* y, int B, int Cin, int Cout,
@@ -1522,8 +1537,7 @@ int tg_poolconv3x3_fwd(const float* x, const float* w4, const float* bias, const
   dim3 grid(geo_tiles(g, B, H, W), (Cout + 15) / 16);
   const int vx = plane_vec_ok(x, 2 * W), vw = tg_aligned16(w4);
   hipStream_t st = tg_stream(stream);
-  if (g == GEO_16) conv_upT_kernel<G16><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, vx, vw);
-  else conv_upT_kernel<GX><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, vx, vw);
+  TG_S2_DISPATCH(g, conv_upT_kernel, x, w4, bias, residual, y, s, vx, vw);
   return tg_launch_status();
 }
 
@@ -1537,8 +1551,7 @@ int tg_poolconv3x3_dgrad(const float* gy, const float* wp, float* gx, int B, int
   dim3 grid(geo_tiles(g, B, H, W), (Cin + 15) / 16);
   const int vx = plane_vec_ok(gy, W), vw = tg_aligned16(wp);
   hipStream_t st = tg_stream(stream);
-  if (g == GEO_16) conv_upfwd_kernel<G16><<<grid, CT_THREADS, 0, st>>>(gy, wp, nullptr, nullptr, gx, s, vx, vw);
-  else conv_upfwd_kernel<GX><<<grid, CT_THREADS, 0, st>>>(gy, wp, nullptr, nullptr, gx, s, vx, vw);
+  TG_S2_DISPATCH(g, conv_upfwd_kernel, gy, wp, nullptr, nullptr, gx, s, vx, vw);
   return tg_launch_status();
 }
 

@@ -331,13 +331,18 @@ class _UpConv3x3(Function):
 
 
 def upconv3x3_pays(a, weight):
-    """True where tg_upconv3x3_fwd runs as ONE kernel (>= 256 workgroups of 256 low-resolution pixels x 16 output
-    channels on planes of 16x16 or more); smaller layers are faster as up2x + the 3x3 kernel."""
+    """True where tg_upconv3x3_fwd runs as ONE kernel (enough workgroups of 256 low-resolution pixels x 16 output
+    channels, source planes of 8x8 or more); smaller layers are faster as up2x + the 3x3 kernel."""
     B, _, H, W = a.shape
-    if H < 16 or W < 16 or (H, W) in ((4, 4), (8, 8)):
+    if (H, W) == (8, 8):
+        tiles, need = (B + 3) // 4, 128
+    elif (H, W) == (16, 16):
+        tiles, need = B, 256
+    elif H >= 8 and W >= 8 and (H, W) != (4, 4):
+        tiles, need = B * ((H + 7) // 8) * ((W + 31) // 32), 256
+    else:
         return False
-    tiles = B if (H, W) == (16, 16) else B * ((H + 7) // 8) * ((W + 31) // 32)
-    return tiles * ((weight.shape[0] + 15) // 16) >= 256
+    return tiles * ((weight.shape[0] + 15) // 16) >= need
 
 
 def upconv3x3(a, weight, bias=None, residual=None):
