@@ -432,7 +432,14 @@ class _PoolConvT(Function):
         if ctx.needs_input_grad[0]:
             a_gy = _PoolConv.apply(v, w, None, None)
         if ctx.needs_input_grad[1]:
-            a_w = _ConvWgrad.apply(v, _Up2x.apply(gy, 0.25), 3)
+            if torch.is_grad_enabled():
+                a_w = _ConvWgrad.apply(v, _Up2x.apply(gy, 0.25), 3)
+            else:                                   # <v, PoolConvT(gy, w)> = <PoolConv(v, w), gy>: the pooled conv's weight gradient
+                B, Cout, H, W = gy.shape
+                Cin = w.shape[1]
+                a_w = torch.empty_like(w)
+                ws = _ws(v, K().poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
+                K().poolconv3x3_wgrad(v, gy, a_w, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0)
         return a_gy, a_w
 
 
