@@ -1128,7 +1128,7 @@ conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, con
 // weight gradients reduce to (pooled conv: lo = gy, hi = x; up-conv: lo = a, hi = gy), 16 taps per low-resolution pixel and
 // channel pair instead of 36 for the 3x3 weight gradient on the (materialised) high-resolution pair.  Same scheme as
 // conv_wgrad_kernel: M = 16 `lo` channels, N = (8 `hi` channels x 16 taps) columns, K = pixels; per-workgroup partials.
-constexpr int S2_CKW = 8, S2_NT = S2_CKW * 16 / 16;
+constexpr int S2_CKW = 4, S2_NT = S2_CKW * 16 / 16;   // (measured: 4 beats 8 and 2 -- 38 KB of LDS, 4 workgroups per CU)
 template <class G>
 __global__ void __launch_bounds__(CT_THREADS)
 conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo, float* __restrict__ part, Shape s /*Cin = hi channels,
