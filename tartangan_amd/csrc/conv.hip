@@ -215,7 +215,7 @@ struct PatchStager {
 //   forward: row = co,  w[co][ci0..ci0+CK][tap]          (element k = ci*KK + tap)
 //   dgrad  : row = ci,  w[ci][co0..co0+CT][KK-1-tap]     (element k = co*KK + tp), w stored [Cin_eff][Cout_eff][KK]
 // (KS code 4: the 16-tap filter rows of the stride-2 transpose kernel, conv_upT_kernel; it only uses the filter stager)
-template <int KS, bool WK> struct FwdCfg { static constexpr int CK = (KS == 3) ? (WK ? 16 : 8) : (KS == 2) ? (WK ? 32 : 16) : (KS == 4) ? 8 : 32; };
+template <int KS, bool WK> struct FwdCfg { static constexpr int CK = (KS == 3) ? (WK ? 16 : 8) : (KS == 2) ? (WK ? 32 : 16) : (KS == 4) ? 4 : 32; };
 
 template <int KS, int CT, bool WK>
 struct WTile {
@@ -1127,7 +1127,7 @@ conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, con
 // The third member of the family: T[o][i][u][v] = sum_{b, r, c} lo[b][o][r][c] * hi[b][i][2r-1+u][2c-1+v], the product both
 // weight gradients reduce to (pooled conv: lo = gy, hi = x; up-conv: lo = a, hi = gy), 16 taps per low-resolution pixel and
 // channel pair instead of 36 for the 3x3 weight gradient on the (materialised) high-resolution pair.  Same scheme as
-// conv_wgrad_kernel: M = 16 `lo` channels, N = (8 `hi` channels x 16 taps) columns, K = pixels; per-workgroup partials.
+// conv_wgrad_kernel: M = 16 `lo` channels, N = (S2_CKW `hi` channels x 16 taps) columns, K = pixels; per-workgroup partials.
 constexpr int S2_CKW = 4, S2_NT = S2_CKW * 16 / 16;   // (measured: 4 beats 8 and 2 -- 38 KB of LDS, 4 workgroups per CU)
 template <class G>
 __global__ void __launch_bounds__(CT_THREADS)
