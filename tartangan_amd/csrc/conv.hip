@@ -1197,27 +1197,42 @@ conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo,
   }
 }
 
-// T -> 3x3 weight gradient.  mode 0 (pooled conv, T[co][ci]):  gw[kh][kw] (+)= 0.25 sum_{dy,dx} T[dy+kh][dx+kw];
-// mode 1 (up-conv, T[ci][co]): gw[kh][kw] (+)= sum_{u: kh in S(u)} sum_{v: kw in S(v)} T[u][v], S = {2},{1,2},{0,1},{0}.
-__global__ void __launch_bounds__(256) s2wgrad_fold_kernel(const float* __restrict__ T, float* __restrict__ gw, int Cout, int Cin, int mode,
-                                                           int accumulate) {
-  const int e = blockIdx.x * 256 + threadIdx.x;          // e = co * Cin + ci
-  if (e >= Cout * Cin) return;
-  const int co = e / Cin, ci = e - co * Cin;
-  const float* t = T + (mode == 0 ? (int64_t)e : (int64_t)ci * Cout + co) * 16;
-  float k[4][4];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) k[i >> 2][i & 3] = t[i];
-#pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int u0 = mode == 0 ? kh : 2 - kh, v0 = mode == 0 ? kw : 2 - kw;      // rows u0, u0 + 1 and columns v0, v0 + 1
-      float r = (k[u0][v0] + k[u0][v0 + 1]) + (k[u0 + 1][v0] + k[u0 + 1][v0 + 1]);
+// Sum of the S partials of T (fixed order) and fold onto the 3x3 taps, in one kernel: a workgroup owns 4 (lo, hi)
+// channel pairs; thread = (pair, tap, S-slice), the 4 slices are combined through LDS, then 9 threads per pair fold.
+//   mode 0 (pooled conv, T[co][ci]):  gw[kh][kw] (+)= 0.25 sum_{dy,dx} T[dy+kh][dx+kw];
+//   mode 1 (up-conv, T[ci][co]):      gw[kh][kw] (+)= sum_{u: kh in S(u)} sum_{v: kw in S(v)} T[u][v], S = {2},{1,2},{0,1},{0}.
+__global__ void __launch_bounds__(256) s2wgrad_reduce_fold_kernel(const float* __restrict__ part, float* __restrict__ gw, int S, int Clo,
+                                                                  int Chi, int Cout, int Cin, int mode, int accumulate) {
+  __shared__ float red[4][4][16];                 // [slice][pair][tap]
+  __shared__ float T[4][16];
+  const int tap = threadIdx.x & 15, pr = (threadIdx.x >> 4) & 3, sl = threadIdx.x >> 6;
+  const int64_t npairs = (int64_t)Clo * Chi;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + pr;    // index into T's [lo][hi] layout
+  float a0 = 0.f, a1 = 0.f;
+  if (pair < npairs) {
+    const float* src = part + pair * 16 + tap;
+    const int64_t stride = npairs * 16;
+    int s = sl;
+    for (; s + 4 < S; s += 8) { a0 += src[(int64_t)s * stride]; a1 += src[(int64_t)(s + 4) * stride]; }
+    for (; s < S; s += 4) a0 += src[(int64_t)s * stride];
+  }
+  red[sl][pr][tap] = a0 + a1;
+  __syncthreads();
+  if (sl == 0) T[pr][tap] = (red[0][pr][tap] + red[1][pr][tap]) + (red[2][pr][tap] + red[3][pr][tap]);
+  __syncthreads();
+  if (threadIdx.x < 36) {
+    const int p = threadIdx.x / 9, k = threadIdx.x % 9, kh = k / 3, kw = k % 3;
+    const int64_t pp = (int64_t)blockIdx.x * 4 + p;
+    if (pp < npairs) {
+      const int lo = (int)(pp / Chi), hi = (int)(pp % Chi);
+      const int co = mode == 0 ? lo : hi, ci = mode == 0 ? hi : lo;
+      const int u0 = mode == 0 ? kh : 2 - kh, v0 = mode == 0 ? kw : 2 - kw;
+      float r = (T[p][u0 * 4 + v0] + T[p][u0 * 4 + v0 + 1]) + (T[p][(u0 + 1) * 4 + v0] + T[p][(u0 + 1) * 4 + v0 + 1]);
       if (mode == 0) r *= 0.25f;
-      float* o = gw + (int64_t)e * 9 + kh * 3 + kw;
+      float* o = gw + ((int64_t)co * Cin + ci) * 9 + k;
       *o = accumulate ? *o + r : r;
     }
+  }
 }
 
 // AvgPool2d(2) o conv3x3 = 0.25 * (transpose of the up-conv with the flipped, transposed filter): the same two kernels
@@ -1472,11 +1487,11 @@ static inline int s2_splits(int tiles, int lo_tiles, int hi_chunks) {
   if (S > tiles) S = tiles;
   return S;
 }
-// workspace: S partials of T plus T itself
+// workspace: S partials of T
 static size_t s2_workspace(int B, int Clo, int Chi, int H, int W) {
   const GeoId g = pick_geo(H, W);
   const int S = s2_splits(geo_tiles(g, B, H, W), (Clo + 15) / 16, (Chi + S2_CKW - 1) / S2_CKW);
-  return ((size_t)S + 1) * Clo * Chi * 16 * sizeof(float);
+  return (size_t)S * Clo * Chi * 16 * sizeof(float);
 }
 static int s2_wgrad(const float* hi, const float* lo, float* gw, float* ws, size_t ws_bytes, int B, int Clo, int Chi, int H, int W,
                     int Cout, int Cin, int mode, int accumulate, hipStream_t st) {
@@ -1489,10 +1504,7 @@ static int s2_wgrad(const float* hi, const float* lo, float* gw, float* ws, size
   dim3 grid(S, lo_tiles, hi_chunks);
   const int vh = plane_vec_ok(hi, 2 * W), vl = plane_vec_ok(lo, W);
   TG_S2_DISPATCH(g, conv_wgrad_s2_kernel, hi, lo, ws, s, tiles, S, vh, vl);
-  const int64_t E = (int64_t)Clo * Chi * 16;
-  float* T = ws + (size_t)S * E;
-  wgrad_reduce_kernel<<<(int)((E + 63) / 64), 256, 0, st>>>(ws, T, E, S, nullptr, nullptr, 0, 0);
-  s2wgrad_fold_kernel<<<(Cout * Cin + 255) / 256, 256, 0, st>>>(T, gw, Cout, Cin, mode, accumulate);
+  s2wgrad_reduce_fold_kernel<<<(Clo * Chi + 3) / 4, 256, 0, st>>>(ws, gw, S, Clo, Chi, Cout, Cin, mode, accumulate);
   return tg_launch_status();
 }
 
