@@ -176,6 +176,40 @@ def test_r1_first_order_pass_skips_parameter_gradients_without_changing_results(
     assert b[3] - a[3] == n_convs           # exactly one wasted weight gradient per discriminator conv is gone
 
 
+@pytest.mark.parametrize('op', ['pool_conv', 'up_conv'])
+def test_stride2_functions_match_torch_including_double_backward(op):
+    """pool_conv3x3 / upconv3x3 against the reference formulation: values, first-order gradients and, for the pooled conv
+    (it sits under the R1 penalty), the gradient of a gradient-norm penalty."""
+    torch.manual_seed(3)
+    B, Cin, Cout = 2, 5, 7
+    x = torch.randn(B, Cin, 16, 16, requires_grad=True)
+    w = torch.nn.Parameter(torch.randn(Cout, Cin, 3, 3) * 0.3)
+    b = torch.nn.Parameter(torch.randn(Cout) * 0.1)
+    F = torch.nn.functional
+    if op == 'pool_conv':
+        ours = lambda: TF.pool_conv3x3(x, w, b)
+        ref = lambda: F.avg_pool2d(F.conv2d(x, w, b, padding=1), 2)
+    else:
+        ours = lambda: TF.upconv3x3(x, w, b)
+        ref = lambda: F.conv2d(F.interpolate(x, scale_factor=2), w, b, padding=1)
+
+    def run(f, second_order):
+        for t in (x, w, b):
+            t.grad = None
+        y = f()
+        if second_order:
+            g, = torch.autograd.grad(y.tanh().sum(), x, create_graph=True)
+            (g.pow(2).sum() + y.sum()).backward()
+        else:
+            y.pow(2).sum().backward()
+        return y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone()
+
+    for second_order in ((False, True) if op == 'pool_conv' else (False,)):
+        got, want = run(ours, second_order), run(ref, second_order)
+        for a_, b_ in zip(got, want):
+            assert torch.allclose(a_, b_, rtol=2e-4, atol=2e-4), (op, second_order, float((a_ - b_).abs().max()))
+
+
 def test_product_has_no_cpu_fallback():
     backend._set_backend_for_testing(None)
     x = torch.zeros(1, 4, 4, 4)
