@@ -160,6 +160,37 @@ def test_stride2_weight_gradients(K, shape):
         run_both(K, 'upconv3x3_wgrad', [a, gyh, w0.clone(), ws, ws.numel() * 4, B, Cin, Cout, H, W, acc], [2], tol=1e-4, scratch=[3])
 
 
+@pytest.mark.parametrize('op', ['pool_conv', 'up_conv'])
+def test_stride2_functions_under_autograd(K, op):
+    """The Functions built on the stride-2 kernels, on the GPU, against plain torch on the CPU: values, first-order
+    gradients and (pooled conv, which sits under the R1 penalty) the gradient of a gradient-norm penalty."""
+    from tartangan_amd import functional as TF
+    F = torch.nn.functional
+    B, Cin, Cout, S = 128, 32, 24, 16                     # enough 16x16 planes for the one-kernel forms
+    x0, w0, b0 = rnd(B, Cin, 2 * S if op == 'pool_conv' else S, 2 * S if op == 'pool_conv' else S), rnd(Cout, Cin, 3, 3, scale=0.2), rnd(Cout, scale=0.1)
+    assert TF.pool_conv3x3_supported(x0.cuda(), w0.cuda()) if op == 'pool_conv' else TF.upconv3x3_pays(x0, w0)
+
+    def run(dev, second_order):
+        x, w, b = (t.detach().clone().to(dev).requires_grad_() for t in (x0, w0, b0))
+        if dev == 'cuda':
+            y = TF.pool_conv3x3(x, w, b) if op == 'pool_conv' else TF.upconv3x3(x, w, b)
+        else:
+            y = F.avg_pool2d(F.conv2d(x, w, b, padding=1), 2) if op == 'pool_conv' else \
+                F.conv2d(F.interpolate(x, scale_factor=2), w, b, padding=1)
+        if second_order:
+            g, = torch.autograd.grad(y.tanh().sum(), x, create_graph=True)
+            (g.pow(2).sum() + y.sum()).backward()
+        else:
+            y.pow(2).sum().backward()
+        return [t.detach().cpu() for t in (y, x.grad, w.grad, b.grad)]
+
+    for second_order in ((False, True) if op == 'pool_conv' else (False,)):
+        got, want = run('cuda', second_order), run('cpu', second_order)
+        for a_, b_ in zip(got, want):
+            scale = float(b_.abs().max())
+            assert float((a_ - b_).abs().max()) <= 2e-4 * scale + 1e-5, (op, second_order)
+
+
 def test_conv_fwd_exact_integer_layout(K):
     """Asymmetric small-integer data: any A/B/C fragment transposition shows up as an exact mismatch."""
     B, Cin, Cout, H, W = 2, 8, 32, 32, 32
