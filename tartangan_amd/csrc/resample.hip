@@ -195,6 +195,55 @@ __global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_plane_kernel(const
   }
 }
 
+// One-hit variant.  With scale = (in - 1) / (out - 1) >= 2 consecutive outputs read disjoint input pairs
+// (floor(s (o + 1)) >= floor(s o) + 2), so every input element receives from AT MOST ONE output per axis: the transpose is
+// a plain gather gx[i][j] = wr[i] * wc[j] * gy[ro[i]][co[j]] (+ residual).  The (index, weight) tables are built once per
+// workgroup from the same fp32 source-index arithmetic as the forward; rows are written as float4.
+constexpr int BL_MAX_AXIS = 512;
+struct OneHit { int o; float w; };
+__global__ void __launch_bounds__(RS_BLOCK) bilinear_half_bwd_onehit_kernel(const float* __restrict__ gy, const float* __restrict__ residual,
+                                                                            float* __restrict__ gx, int BC, int H, int W, int OH, int OW,
+                                                                            float sh, float sw) {
+  __shared__ OneHit rows[BL_MAX_AXIS], cols[BL_MAX_AXIS];
+  for (int i = threadIdx.x; i < H + W; i += RS_BLOCK) {
+    const bool is_row = i < H;
+    const int in = is_row ? i : i - H;
+    const float sc = is_row ? sh : sw;
+    const int in_size = is_row ? H : W, out_size = is_row ? OH : OW;
+    int lo = (int)((float)(in - 1) / sc) - 1;
+    lo = lo < 0 ? 0 : lo;
+    OneHit e{0, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float w = (lo + u < out_size) ? axis_weight(lo + u, in, sc, in_size) : 0.f;
+      if (w != 0.f) { e.o = lo + u; e.w = w; }
+    }
+    if (is_row) rows[in] = e; else cols[in] = e;
+  }
+  __syncthreads();
+  const int nin = H * W, nout = OH * OW, q4 = W >> 2;            // W % 4 == 0 (host-checked)
+  for (int plane = blockIdx.x; plane < BC; plane += gridDim.x) {
+    const float* gp = gy + (int64_t)plane * nout;
+    float* xp = gx + (int64_t)plane * nin;
+    const float* rp = residual ? residual + (int64_t)plane * nin : nullptr;
+    for (int e = threadIdx.x; e < H * q4; e += RS_BLOCK) {
+      const int h = e / q4, w0 = (e - h * q4) * 4;
+      const OneHit r = rows[h];
+      const float* grow = gp + r.o * OW;
+      float4 o;
+      { const OneHit c = cols[w0];     o.x = r.w * c.w * grow[c.o]; }
+      { const OneHit c = cols[w0 + 1]; o.y = r.w * c.w * grow[c.o]; }
+      { const OneHit c = cols[w0 + 2]; o.z = r.w * c.w * grow[c.o]; }
+      { const OneHit c = cols[w0 + 3]; o.w = r.w * c.w * grow[c.o]; }
+      if (rp) {
+        const float4 rr = *reinterpret_cast<const float4*>(rp + (int64_t)h * W + w0);
+        o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+      }
+      *reinterpret_cast<float4*>(xp + (int64_t)h * W + w0) = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ 2x2 max pool
 __global__ void __launch_bounds__(RS_BLOCK) maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 uint8_t* __restrict__ idx, int64_t nout, int H, int W) {
@@ -293,6 +342,14 @@ int tg_bilinear_half_bwd(const float* gy, const float* residual, float* gx, int 
   if (H < 2 || W < 2) return TG_EUNSUPPORTED;
   const int OH = H / 2, OW = W / 2;
   const int64_t nin = (int64_t)BC * H * W;
+  if (OH >= 2 && OW >= 2 && W % 4 == 0 && H <= BL_MAX_AXIS && W <= BL_MAX_AXIS && H * W >= 256 && tg_aligned16(gx) &&
+      (!residual || tg_aligned16(residual))) {
+    // scale = (in - 1) / (out - 1) > 2 for out = in / 2: one contributing output per axis
+    const int grid = BC < 4096 ? BC : 4096;
+    bilinear_half_bwd_onehit_kernel<<<grid, RS_BLOCK, 0, tg_stream(stream)>>>(gy, residual, gx, BC, H, W, OH, OW, ac_scale(H, OH),
+                                                                              ac_scale(W, OW));
+    return tg_launch_status();
+  }
   if (H <= 128 && W <= 128 && OH * OW <= BL_MAX_OUT && H * W >= 256) {
     const int grid = BC < 2048 ? BC : 2048;
     bilinear_half_bwd_plane_kernel<<<grid, RS_BLOCK, 0, tg_stream(stream)>>>(gy, residual, gx, BC, H, W, OH, OW, ac_scale(H, OH),

@@ -305,7 +305,7 @@ def test_batchnorm_all_passes(K, shape):
                                         torch.zeros(B, C, HW), torch.zeros(C), ws, B, C, HW], [10, 11, 12], tol=5e-5)
 
 
-@pytest.mark.parametrize('shape', [(6, 4, 4), (8, 16, 16), (3, 64, 64), (5, 10, 6)])
+@pytest.mark.parametrize('shape', [(6, 4, 4), (8, 16, 16), (3, 64, 64), (5, 10, 6), (4, 128, 128), (3, 34, 20), (2, 256, 64), (5000, 16, 16)])
 def test_resample(K, shape):
     BC, H, W = shape
     x = rnd(BC, H, W)
