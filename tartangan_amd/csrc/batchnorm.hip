@@ -611,7 +611,7 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, cons
   TG_CHECK_PTR(beta); TG_CHECK_PTR(adj_gz); TG_CHECK_PTR(adj_x); TG_CHECK_PTR(adj_gamma); TG_CHECK_PTR(workspace);
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   hipStream_t st = tg_stream(stream);
-  if (small_case(B, C, HW)) {
+  if (small_case(B, C, HW) && (int64_t)B * HW <= 4096) {
     bn_small_dbwd_kernel<<<C, SB, 0, st>>>(v, vgamma, vbeta, gz, x, mean, invstd, gamma, beta, slope, adj_gz, adj_x, adj_gamma,
                                               B, C, HW);
     return tg_launch_status();
