@@ -7,6 +7,7 @@ Implemented: ``DiscriminatorInput`` (discriminator.py:11-22),
 """
 import functools
 
+import torch
 from torch import nn
 
 from ... import functional as TF
@@ -58,6 +59,33 @@ class ResidualDiscriminatorBlock(nn.Module):
         if self.project_input is not None:
             shortcut = run_layers(self.project_input, shortcut)
         return run_layers(self.convs, x, residual=shortcut)          # x + h, the add fused into the avg-pool
+
+    # ---- the first block fused with the from-RGB 1x1 convolution in front of it
+    def fuses_with(self, rgb):
+        """True if ``rgb`` (a DiscriminatorInput) followed by this block can run as ``forward_from_rgb``: the block starts
+        with a plain 3x3 convolution (first_block: no norm / activation in between), keeps its width and uses the
+        default resampling."""
+        mods = list(self.convs)
+        rc = list(getattr(rgb, 'convs', []))
+        return (isinstance(rgb, DiscriminatorInput) and len(rc) == 1 and type(rc[0]) is Conv2d and rc[0].kernel_size == (1, 1)
+                and rc[0].bias is not None and len(mods) > 1 and type(mods[0]) is Conv2d and mods[0].kernel_size == (3, 3)
+                and self.project_input is None and self.interpolate is _half)
+
+    def forward_from_rgb(self, img, rgb):
+        """block(rgb(img)) with the two linear maps in front composed (discriminator.py:11-22 + :60-61: a 1x1 convolution
+        directly followed by a 3x3 one).  W'[co][c][tap] = sum_m W3[co][m][tap] W1[m][c]; the from-RGB bias rides on an
+        extra all-ones input channel so that zero padding treats it exactly like the reference does at the borders.
+        One 4->C 3x3 convolution replaces a 3->C 1x1 and a C->C 3x3 one (C = 16 at 128 px: 4x fewer multiply-adds at
+        the full resolution), and the shortcut's bilinear-1/2 runs on the 3-channel image (it commutes with the 1x1)."""
+        rgb_conv, conv1 = rgb.convs[0], self.convs[0]
+        C, Cimg = rgb_conv.weight.shape[:2]
+        Cout = conv1.weight.shape[0]
+        w1 = torch.cat([rgb_conv.weight.view(C, Cimg), rgb_conv.bias.view(C, 1)], 1)                  # (C, Cimg + 1)
+        wc = TF.matmul(w1.unsqueeze(0).expand(Cout, C, Cimg + 1), conv1.weight.view(Cout, C, 9), transA=True)
+        ones = img.new_ones(img.shape[0], 1, img.shape[2], img.shape[3])
+        h = TF.conv2d(torch.cat([img, ones], 1), wc.view(Cout, Cimg + 1, 3, 3), conv1.bias)
+        shortcut = run_layers(rgb.convs, self.interpolate(img))
+        return run_layers(self.convs[1:], h, residual=shortcut)
 
 
 class DiscriminatorOutput(nn.Module):

@@ -91,6 +91,15 @@ class Discriminator(BlockModel):
         stages.append(self.output_factory(width, 1))
         self.blocks = nn.Sequential(*stages)
 
+    def forward(self, x):
+        blocks = list(self.blocks)
+        if len(blocks) > 1 and getattr(blocks[1], 'fuses_with', lambda _: False)(blocks[0]):
+            x = blocks[1].forward_from_rgb(x, blocks[0])        # from-RGB 1x1 composed into the first block's 3x3
+            blocks = blocks[2:]
+        for block in blocks:
+            x = block(x)
+        return x
+
 
 class IQNDiscriminator(Discriminator):
     """No from-RGB conv: the first residual block runs on the 3 image channels; the
