@@ -291,7 +291,7 @@ def main():
                                              **({'tflops': round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2)} if d['flops'] else {})}
                                          for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
                 out['kernel_time_ms']['_sum_of_timed_launches'] = round(total, 4)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:       # reported at N = 1 only
             out['cpu_baseline'] = cpu_baseline(a.config, a.trainer, a.cpu_batch)
         print(json.dumps(out), flush=True)
     if world > 1:
