@@ -248,6 +248,18 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     value = a.batch * world * a.steps / dt
 
+    agg = {}
+    if not a.no_kernel_timing:
+        # instrumented eager pass of the same step (same kernels, same shapes) with HIP events on the launch stream;
+        # every rank runs it (the step's collectives must stay matched), rank 0 reports its own kernels
+        saved = (getattr(tr, '_graphs', None), getattr(tr, '_graph_requested', False), tr.rng_feed.mode)
+        tr._graphs, tr._graph_requested = None, False
+        tr.rng_feed.mode = 'off'
+        with KernelTimer(K) as kt:
+            tr.train_batch(imgs)
+        agg = kt.summary()
+        tr._graphs, tr._graph_requested, tr.rng_feed.mode = saved
+
     if rank == 0:
         out = {
             'metric': 'images/sec (G+D step)', 'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world,
@@ -266,31 +278,22 @@ def main():
             out['roofline_step'] = {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': MFMA_F32_PEAK_TFLOPS,
                                     'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                                     'flop_per_image': flop_img}
-        if not a.no_kernel_timing:
-            # instrumented eager pass of the same step (same kernels, same shapes) with HIP events
-            saved = (getattr(tr, '_graphs', None), getattr(tr, '_graph_requested', False), tr.rng_feed.mode)
-            tr._graphs, tr._graph_requested = None, False
-            tr.rng_feed.mode = 'off'
-            with KernelTimer(K) as kt:
-                tr.train_batch(imgs) if world == 1 else None
-            agg = kt.summary() if world == 1 else {}
-            tr._graphs, tr._graph_requested, tr.rng_feed.mode = saved
-            if agg:
-                conv = {k: sum(agg[n][k] for n in CONV_FAMILY if n in agg) for k in ('ms', 'launches', 'flops', 'bytes')}
-                ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
-                out['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA implicit-GEMM conv family: conv_fwd_kernel (fwd + dgrad), conv_upfwd_kernel, conv_upT_kernel',
-                                   'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                   'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                                   'traffic': hbm_traffic_per_launch(a, agg),
-                                   'algorithmic_bytes_per_launch': round(conv['bytes'] / conv['launches']),
-                                   'launches_per_step': conv['launches'],
-                                   'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
-                                   'algorithmic_flop_per_step': conv['flops']}
-                total = sum(d['ms'] for d in agg.values())
-                out['kernel_time_ms'] = {k: {'ms': round(d['ms'], 4), 'launches': d['launches'],
-                                             **({'tflops': round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2)} if d['flops'] else {})}
-                                         for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
-                out['kernel_time_ms']['_sum_of_timed_launches'] = round(total, 4)
+        if agg:
+            conv = {k: sum(agg[n][k] for n in CONV_FAMILY if n in agg) for k in ('ms', 'launches', 'flops', 'bytes')}
+            ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA implicit-GEMM conv family: conv_fwd_kernel (fwd + dgrad), conv_upfwd_kernel, conv_upT_kernel',
+                               'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                               'traffic': hbm_traffic_per_launch(a, agg),
+                               'algorithmic_bytes_per_launch': round(conv['bytes'] / conv['launches']),
+                               'launches_per_step': conv['launches'],
+                               'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
+                               'algorithmic_flop_per_step': conv['flops']}
+            total = sum(d['ms'] for d in agg.values())
+            out['kernel_time_ms'] = {k: {'ms': round(d['ms'], 4), 'launches': d['launches'],
+                                         **({'tflops': round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2)} if d['flops'] else {})}
+                                     for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
+            out['kernel_time_ms']['_sum_of_timed_launches'] = round(total, 4)
         if not a.no_cpu_baseline and world == 1:       # reported at N = 1 only
             out['cpu_baseline'] = cpu_baseline(a.config, a.trainer, a.cpu_batch)
         print(json.dumps(out), flush=True)
