@@ -215,7 +215,7 @@ struct PatchStager {
 //   forward: row = co,  w[co][ci0..ci0+CK][tap]          (element k = ci*KK + tap)
 //   dgrad  : row = ci,  w[ci][co0..co0+CT][KK-1-tap]     (element k = co*KK + tp), w stored [Cin_eff][Cout_eff][KK]
 // (KS code 4: the 16-tap filter rows of the stride-2 transpose kernel, conv_upT_kernel; it only uses the filter stager)
-template <int KS, bool WK> struct FwdCfg { static constexpr int CK = (KS == 3) ? (WK ? 16 : 8) : (KS == 2) ? (WK ? 32 : 16) : (KS == 4) ? 4 : 32; };
+template <int KS, bool WK> struct FwdCfg { static constexpr int CK = (KS == 3) ? (WK ? 16 : 8) : (KS == 2) ? (WK ? 32 : 16) : (KS == 4) ? (WK ? 16 : 4) : 32; };
 
 template <int KS, int CT, bool WK>
 struct WTile {
@@ -853,27 +853,31 @@ __global__ void __launch_bounds__(256) upconv_weights_kernel(const float* __rest
 // is read once per k-group and feeds the phases whose 2x2 window covers it (16 (phase, tap) products per channel), each
 // phase into its own accumulators; the epilogue writes the two horizontally adjacent phases as one float2.  16-channel
 // output tiles (64 accumulator registers per lane).
-template <class G>
+// WK (64-pixel tiles for planes that give too few 256-pixel ones): the waves share the pixels and split the k-groups of a
+// chunk; the partial sums meet in LDS two phases at a time and wave n stores pixel sub-tile n.
+template <class G, bool WK>
 __global__ void __launch_bounds__(CT_THREADS)
 conv_upfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                   const float* __restrict__ residual, float* __restrict__ y, Shape s, int vec_x, int vec_w) {
   constexpr int KS = 2, CT = 16, NT = 4, KG = 4;
   using P = Patch<G, KS>;
-  using WT = WTile<KS, CT, false>;
-  constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS, NG = CK / KG;
-  static_assert(G::NPIX == 256 && KK == 4, "256-pixel tiles, 2x2 windows");
-  __shared__ __attribute__((aligned(16))) float lds[CK * P::CIS + 4 * WT::SIZE];
+  using WT = WTile<KS, CT, WK>;
+  constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS, NG = CK / KG, GSTEP = WK ? 4 : 1;
+  static_assert(G::NPIX == (WK ? 64 : 256) && KK == 4 && NG % GSTEP == 0, "256-pixel tiles (or 64, K split over the waves), 2x2 windows");
+  constexpr int STAGE = CK * P::CIS + 4 * WT::SIZE, REDF = WK ? 4 * 2 * NT * 4 * 64 : 0;
+  __shared__ __attribute__((aligned(16))) float lds[STAGE > REDF ? STAGE : REDF];
   float* pl = lds;
   float* wl = lds + CK * P::CIS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, h = lane >> 4;
   const TileCoord tc = decode_tile<G>(blockIdx.x, s.H, s.W);
   const int co0 = blockIdx.y * CT;
-  const int pix0 = wave * 64;
+  const int pix0 = WK ? 0 : wave * 64;
+  const int k0 = WK ? wave * KG : 0;                  // WK: wave w takes k-groups w, w + 4, ...
   int lane_b[NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) lane_b[n] = h * P::CIS + pix_off<G, KS>(pix0 + n * 16 + j);
-  const int lane_a = (h * KK) * CTS + j;
+  for (int n = 0; n < NT; ++n) lane_b[n] = (h + k0) * P::CIS + pix_off<G, KS>(pix0 + n * 16 + j);
+  const int lane_a = ((h + k0) * KK) * CTS + j;
   f32x4 acc[4][NT];
 #pragma unroll
   for (int ph = 0; ph < 4; ++ph)
@@ -881,7 +885,7 @@ conv_upfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, con
     for (int n = 0; n < NT; ++n) acc[ph][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   PatchStager<G, KS, CK> ps;
-  WeightStager<KS, CT, false, false> ws[4];
+  WeightStager<KS, CT, false, WK> ws[4];
   const size_t phase_stride = (size_t)s.Cout * s.Cin * KK;
   ps.load(x, s, s.Cin, 0, tc, vec_x);
 #pragma unroll
@@ -898,7 +902,8 @@ conv_upfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, con
       for (int ph = 0; ph < 4; ++ph) ws[ph].load(wp + ph * phase_stride, s.Cin, s.Cout, ci0 + CK, co0, vec_w);
     }
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int gi = 0; gi < NG / GSTEP; ++gi) {
+      const int g = gi * GSTEP;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -918,6 +923,35 @@ conv_upfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, con
                 acc[dy * 2 + dx][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[dy * 2 + dx][n], 0, 0, 0);
             }
         }
+    }
+  }
+
+  if constexpr (WK) {
+    // two phases (one output row parity) per pass through LDS; wave n keeps the sums of pixel sub-tile n
+    float* red = lds;
+    constexpr int PW_ = 2 * NT * 4 * 64;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      __syncthreads();
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[wave * PW_ + ((dx * NT + n) * 4 + r) * 64 + lane] = acc[dy * 2 + dx][n][r];
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        if (n != wave) continue;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = ((dx * NT + n) * 4 + r) * 64 + lane;
+            acc[dy * 2 + dx][n][r] = (red[e] + red[PW_ + e]) + (red[2 * PW_ + e] + red[3 * PW_ + e]);
+          }
+      }
+    }
   }
 
   // epilogue: y[b][co][2(h0+pr)+dy][2(w0+pc)+dx]; the dx pair of a lane is one aligned float2
@@ -931,6 +965,7 @@ conv_upfwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, con
   for (int r = 0; r < 4; ++r) bv[r] = bias ? bias[min(co0 + 4 * h + r, s.Cout - 1)] : 0.f;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
+    if (WK && n != wave) continue;
     const int p = pix0 + n * 16 + j;
     const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
     const int pr = rem / G::TW, pc = rem % G::TW;
@@ -1069,36 +1104,40 @@ struct PatchStager2x {
   }
 };
 
-template <class G>
+// WK (64-pixel tiles, used when 256-pixel tiles would leave CUs idle): the four waves share the pixels and split the
+// 16 channels of a chunk, partial sums meet in LDS (as in conv_fwd_kernel).
+template <class G, bool WK>
 __global__ void __launch_bounds__(CT_THREADS)
 conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, const float* __restrict__ bias,
                 const float* __restrict__ residual, float* __restrict__ ga, Shape s /*Cin = gy channels, Cout = ga channels,
                 H x W = ga plane*/, int vec_x, int vec_w) {
   constexpr int CT = 16, NT = 4, KG = 4;
   using P = Patch2x<G>;
-  using WT = WTile<4, CT, false>;                     // 16 taps per (out, in) channel pair
+  using WT = WTile<4, CT, WK>;                        // 16 taps per (out, in) channel pair
   constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS, NG = CK / KG;
-  static_assert(KK == 16 && G::NPIX == 256, "16 taps, 256-pixel tiles");
-  __shared__ __attribute__((aligned(16))) float lds[CK * P::CIS + WT::SIZE];
+  static_assert(KK == 16 && G::NPIX == (WK ? 64 : 256) && (!WK || NG == 4), "16 taps; 256-pixel tiles, or 64 with one k-group per wave");
+  constexpr int STAGE = CK * P::CIS + WT::SIZE, REDF = WK ? 4 * NT * 4 * 64 : 0;
+  __shared__ __attribute__((aligned(16))) float lds[STAGE > REDF ? STAGE : REDF];
   float* pl = lds;
   float* wl = lds + CK * P::CIS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, h = lane >> 4;
   const TileCoord tc = decode_tile<G>(blockIdx.x, s.H, s.W);
   const int co0 = blockIdx.y * CT;
-  const int pix0 = wave * 64;
+  const int pix0 = WK ? 0 : wave * 64;
+  const int k0 = WK ? wave * KG : 0;                  // first channel (inside a chunk) of this wave's k-group
   int lane_b[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    lane_b[n] = h * P::CIS + P::pix(pix0 + n * 16 + j);
+    lane_b[n] = (h + k0) * P::CIS + P::pix(pix0 + n * 16 + j);
   }
-  const int lane_a = (h * KK) * CTS + j;
-  using Core = FwdCore<G, 3, 16, 1, false>;
+  const int lane_a = ((h + k0) * KK) * CTS + j;
+  using Core = FwdCore<G, 3, 16, 1, WK>;
   typename Core::acc_t acc[1][NT];
   Core::zero(acc);
 
   PatchStager2x<G, CK> ps;
-  WeightStager<4, CT, false, false> ws;
+  WeightStager<4, CT, false, WK> ws;
   const int H2 = 2 * s.H, W2 = 2 * s.W;
   ps.load(gy, s.B, s.Cin, H2, W2, 0, tc, vec_x);
   ws.load(w4t, s.Cin, s.Cout, 0, co0, vec_w);
@@ -1112,13 +1151,30 @@ conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, con
       ws.load(w4t, s.Cin, s.Cout, ci0 + CK, co0, vec_w);
     }
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int g = 0; g < (WK ? 1 : NG); ++g)
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const float a = wl[lane_a + ((g * KG) * KK + t) * CTS];
 #pragma unroll
         for (int n = 0; n < NT; ++n)
           acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[lane_b[n] + (g * KG) * P::CIS + (t >> 2) * P::PWS + (t & 3)], acc[0][n], 0, 0, 0);
+      }
+  }
+  if constexpr (WK) {
+    __syncthreads();
+    float* red = lds;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * NT + n) * 4 + r) * 64 + lane] = acc[0][n][r];
+    __syncthreads();
+    constexpr int PW_ = NT * 4 * 64;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = (n * 4 + r) * 64 + lane;
+        acc[0][n][r] = (red[e] + red[PW_ + e]) + (red[2 * PW_ + e] + red[3 * PW_ + e]);
       }
   }
   Core::epilogue(acc, bias, residual, ga, s, tc, co0, pix0, j, h, wave);
@@ -1303,6 +1359,33 @@ static inline int64_t s2_min_wgs(GeoId g) { return g == GEO_8 ? 128 : 256; }
     else KERNEL<GX><<<grid, CT_THREADS, 0, st>>>(__VA_ARGS__);                           \
   } while (0)
 
+// stride-2 transpose form: 8x8 planes that give fewer than 256 four-image tiles run as single-image K-split tiles
+static void launch_upT(GeoId g, const float* x, const float* w4, const float* bias, const float* residual, float* y, Shape s,
+                       int vx, int vw, hipStream_t st) {
+  const int cot = (s.Cout + 15) / 16;
+  if (g == GEO_8 && (int64_t)geo_tiles(g, s.B, s.H, s.W) * cot < 256) {
+    conv_upT_kernel<G8k, true><<<dim3(num_tiles<G8k>(s.B, s.H, s.W), cot), CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, vx, vw);
+    return;
+  }
+  dim3 grid(geo_tiles(g, s.B, s.H, s.W), cot);
+  if (g == GEO_8) conv_upT_kernel<G8, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, vx, vw);
+  else if (g == GEO_16) conv_upT_kernel<G16, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, vx, vw);
+  else conv_upT_kernel<GX, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, vx, vw);
+}
+
+static void launch_upfwd(GeoId g, const float* x, const float* wp, const float* bias, const float* residual, float* y, Shape s,
+                         int vx, int vw, hipStream_t st) {
+  const int cot = (s.Cout + 15) / 16;
+  if (g == GEO_8 && (int64_t)geo_tiles(g, s.B, s.H, s.W) * cot < 256) {
+    conv_upfwd_kernel<G8k, true><<<dim3(num_tiles<G8k>(s.B, s.H, s.W), cot), CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, vx, vw);
+    return;
+  }
+  dim3 grid(geo_tiles(g, s.B, s.H, s.W), cot);
+  if (g == GEO_8) conv_upfwd_kernel<G8, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, vx, vw);
+  else if (g == GEO_16) conv_upfwd_kernel<G16, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, vx, vw);
+  else conv_upfwd_kernel<GX, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, vx, vw);
+}
+
 template <class G, int KS, bool DGRAD>
 int launch_fwd_geo(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
   const int tiles = num_tiles<G>(s.B, s.H, s.W);
@@ -1439,8 +1522,7 @@ int tg_upconv3x3_fwd(const float* a, const float* wp, const float* bias, const f
     const bool aligned8 = (((uintptr_t)y & 7) == 0) && (!residual || ((uintptr_t)residual & 7) == 0);
     if (s2_geo(g) && aligned8 && (int64_t)geo_tiles(g, B, H, W) * cot >= s2_min_wgs(g)) {
       const int vx = plane_vec_ok(a, W), vw = tg_aligned16(wp);
-      dim3 grid(geo_tiles(g, B, H, W), cot);
-      TG_S2_DISPATCH(g, conv_upfwd_kernel, a, wp, bias, residual, y, s, vx, vw);
+      launch_upfwd(g, a, wp, bias, residual, y, s, vx, vw, st);
       return tg_launch_status();
     }
   }
@@ -1472,10 +1554,8 @@ int tg_upconv3x3_dgrad(const float* gy, const float* w4t, float* ga, int B, int 
   // a convolution whose input channels are the forward's Cout (gy) and output channels its Cin (ga)
   Shape s{B, Cout, Cin, H, W};
   const GeoId g = pick_geo(H, W);
-  dim3 grid(geo_tiles(g, B, H, W), (Cin + 15) / 16);
   const int vx = plane_vec_ok(gy, 2 * W), vw = tg_aligned16(w4t);
-  hipStream_t st = tg_stream(stream);
-  TG_S2_DISPATCH(g, conv_upT_kernel, gy, w4t, nullptr, nullptr, ga, s, vx, vw);
+  launch_upT(g, gy, w4t, nullptr, nullptr, ga, s, vx, vw, tg_stream(stream));
   return tg_launch_status();
 }
 
@@ -1546,10 +1626,8 @@ int tg_poolconv3x3_fwd(const float* x, const float* w4, const float* bias, const
   if (!tg_poolconv3x3_supported(B, Cin, Cout, H, W)) return TG_EUNSUPPORTED;
   Shape s{B, Cin, Cout, H, W};
   const GeoId g = pick_geo(H, W);
-  dim3 grid(geo_tiles(g, B, H, W), (Cout + 15) / 16);
   const int vx = plane_vec_ok(x, 2 * W), vw = tg_aligned16(w4);
-  hipStream_t st = tg_stream(stream);
-  TG_S2_DISPATCH(g, conv_upT_kernel, x, w4, bias, residual, y, s, vx, vw);
+  launch_upT(g, x, w4, bias, residual, y, s, vx, vw, tg_stream(stream));
   return tg_launch_status();
 }
 
@@ -1560,10 +1638,8 @@ int tg_poolconv3x3_dgrad(const float* gy, const float* wp, float* gx, int B, int
   // the four-phase kernel with gy (Cout channels, H x W) as its low-resolution input and Cin output channels
   Shape s{B, Cout, Cin, H, W};
   const GeoId g = pick_geo(H, W);
-  dim3 grid(geo_tiles(g, B, H, W), (Cin + 15) / 16);
   const int vx = plane_vec_ok(gy, W), vw = tg_aligned16(wp);
-  hipStream_t st = tg_stream(stream);
-  TG_S2_DISPATCH(g, conv_upfwd_kernel, gy, wp, nullptr, nullptr, gx, s, vx, vw);
+  launch_upfwd(g, gy, wp, nullptr, nullptr, gx, s, vx, vw, tg_stream(stream));
   return tg_launch_status();
 }
 

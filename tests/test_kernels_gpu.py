@@ -77,7 +77,7 @@ UPCONV_SHAPES = [(2, 16, 16, 16, 16), (3, 8, 20, 8, 8), (2, 32, 16, 64, 64), (4,
                  # enough low-resolution tiles for the all-phases-in-one kernel (aligned, 16x16 planes, ragged)
                  (16, 32, 16, 64, 64), (128, 8, 24, 16, 16), (20, 12, 10, 70, 50), (64, 64, 32, 32, 32),
                  # 8x8 source planes: 4 images per tile (full and ragged batch)
-                 (64, 128, 128, 8, 8), (258, 24, 40, 8, 8)]
+                 (64, 128, 128, 8, 8), (258, 24, 40, 8, 8), (520, 24, 20, 8, 8)]
 
 
 @pytest.mark.parametrize('shape', UPCONV_SHAPES)
@@ -98,7 +98,7 @@ def test_upconv3x3(K, shape):
 
 
 @pytest.mark.parametrize('shape', [(16, 32, 16, 64, 64), (128, 32, 24, 16, 16), (20, 20, 10, 70, 50), (64, 64, 32, 32, 32), (8, 70, 9, 128, 32),
-                                   (64, 128, 128, 8, 8), (258, 40, 24, 8, 8)])
+                                   (64, 128, 128, 8, 8), (258, 40, 24, 8, 8), (520, 24, 20, 8, 8)])
 def test_upconv3x3_dgrad(K, shape):
     """stride-2 4x4 transpose kernel == pool2x2sum(dgrad3x3(gy)) == autograd's gradient of conv3x3(up2x(a))."""
     B, Cin, Cout, H, W = shape
@@ -117,7 +117,7 @@ def test_upconv3x3_dgrad(K, shape):
 
 
 @pytest.mark.parametrize('shape', [(16, 16, 16, 64, 64), (128, 32, 24, 16, 16), (20, 20, 18, 70, 50), (64, 64, 64, 16, 16), (8, 40, 33, 128, 32),
-                                   (64, 128, 128, 8, 8), (258, 40, 36, 8, 8)])
+                                   (64, 128, 128, 8, 8), (258, 40, 36, 8, 8), (520, 24, 20, 8, 8)])
 def test_poolconv3x3(K, shape):
     """AvgPool2d(2) o conv3x3 as one stride-2 kernel, and its input gradient as the four-phase kernel."""
     B, Cin, Cout, H, W = shape            # H x W = pooled output plane
