@@ -233,8 +233,8 @@ int tg_softmax_dbwd(const float* v, const float* gy, const float* y, float* out,
  * theta (B,D,N), phi (B,D,M), g (B,DV,M), o (B,DV,N), lse (B,N) = log sum_m exp(score).
  * Compiled for (D,DV) in {(1,4),(2,8),(4,16),(8,32),(16,64)} (C = 8..128); others: TG_EUNSUPPORTED
  * (the host then composes tg_gemm / tg_softmax_*).  _bwd is the first-order backward;
- * workspace: tg_attn_bwd_workspace() bytes.  The second-order path recomputes through the composed
- * primitives.                                                                                          */
+ * workspace: tg_attn_bwd_workspace() bytes.  Second order (the R1 penalty differentiates _bwd): the
+ * host forms the (N x M) maps with tg_gemm and calls tg_attn_dbwd_rows for everything row-wise.       */
 int tg_attn_supported(int D, int DV);
 size_t tg_attn_bwd_workspace(int B, int D, int DV, int N, int M);
 int tg_attn_fwd(const float* theta, const float* phi, const float* g, float* o, float* lse,
@@ -242,6 +242,12 @@ int tg_attn_fwd(const float* theta, const float* phi, const float* g, float* o, 
 int tg_attn_bwd(const float* go, const float* theta, const float* phi, const float* g, const float* o,
                 const float* lse, float* dtheta, float* dphi, float* dg, float* workspace,
                 int B, int D, int DV, int N, int M, void* stream);
+/* Row-wise middle of the derivative of tg_attn_bwd.  With a, b, c the adjoints of (dtheta, dphi, dg), on entry
+ *   s = theta^T phi,  gp = go^T g,  u = a^T phi + theta^T b,  v = go^T c      (rows = B*N, cols = M, lse as tg_attn_fwd)
+ * and on return, in place (P = exp(s - lse); delta, eps, zeta = row sums of P gp, P u, P dP):
+ *   s <- P,  gp <- gS = P (gp - delta),  u <- dgP = P (u - eps),  v <- dS = P (dP - zeta),  dP = v + u (gp - delta) - gp eps
+ * from which  d theta = phi dS^T + b gS^T,  d phi = theta dS + a gS,  d go = g dgP^T + c P^T,  d g = go dgP.          */
+int tg_attn_dbwd_rows(float* s, const float* lse, float* gp, float* u, float* v, int rows, int cols, void* stream);
 
 /* ---------------------------------------------------------------- IQN head (models/iqn.py)
  * out[i][j] = cos((taus[i] * pi) * range[j])   iqn.py:41-45 (fp32, this evaluation order) */

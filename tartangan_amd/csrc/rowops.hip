@@ -1,5 +1,7 @@
 // Row / channel reductions and broadcasts, softmax (fwd, bwd, second-order term).
 // One wave (64 lanes) per row; row sums are wavefront shuffles, no LDS, no atomics.
+#include <type_traits>
+
 #include "planes.h"
 
 namespace {
@@ -127,6 +129,57 @@ __global__ void __launch_bounds__(RB) softmax_dbwd_kernel(const float* __restric
   }
 }
 
+// Second-order attention, the row-wise middle of it (see tg_attn_dbwd_rows): per row of the (N x M) maps
+//   P = exp(S - lse),  delta = sum P gP,  eps = sum P U,  zeta = sum P dP = sum P V + sum P U gP - 2 delta eps,
+//   gS = P (gP - delta),  dgP = P (U - eps),  dP = V + U (gP - delta) - gP eps,  dS = P (dP - zeta);
+// every output overwrites the input it replaces (same element, same thread).
+template <bool VEC>
+__global__ void __launch_bounds__(RB) attn_dbwd_rows_kernel(float* __restrict__ s, const float* __restrict__ lse, float* __restrict__ gp,
+                                                            float* __restrict__ u, float* __restrict__ v, int rows, int cols) {
+  using T = typename std::conditional<VEC, float4, float>::type;
+  constexpr int W = VEC ? 4 : 1;
+  const int lane = threadIdx.x & 63;
+  const int nq = cols / W;
+  for (int r = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); r < rows; r += gridDim.x * ROWS_PER_BLOCK) {
+    const int64_t base = (int64_t)r * cols;
+    const float l = lse[r];
+    float d = 0.f, e = 0.f, pv = 0.f, pug = 0.f;
+    for (int q = lane; q < nq; q += 64) {
+      const T sv = *reinterpret_cast<const T*>(s + base + q * W), gv = *reinterpret_cast<const T*>(gp + base + q * W);
+      const T uv = *reinterpret_cast<const T*>(u + base + q * W), vv = *reinterpret_cast<const T*>(v + base + q * W);
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const float p = expf(reinterpret_cast<const float*>(&sv)[k] - l);
+        const float g = reinterpret_cast<const float*>(&gv)[k], uu = reinterpret_cast<const float*>(&uv)[k];
+        d += p * g; e += p * uu; pv += p * reinterpret_cast<const float*>(&vv)[k]; pug += p * uu * g;
+      }
+    }
+    d = wave_sum(d); e = wave_sum(e); pv = wave_sum(pv); pug = wave_sum(pug);
+    const float z = pv + pug - 2.f * d * e;
+    for (int q = lane; q < nq; q += 64) {
+      T sv = *reinterpret_cast<const T*>(s + base + q * W), gv = *reinterpret_cast<const T*>(gp + base + q * W);
+      T uv = *reinterpret_cast<const T*>(u + base + q * W), vv = *reinterpret_cast<const T*>(v + base + q * W);
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        float& sp = reinterpret_cast<float*>(&sv)[k];
+        float& g = reinterpret_cast<float*>(&gv)[k];
+        float& uu = reinterpret_cast<float*>(&uv)[k];
+        float& ww = reinterpret_cast<float*>(&vv)[k];
+        const float p = expf(sp - l);
+        const float dp = ww + uu * (g - d) - g * e;
+        sp = p;
+        ww = p * (dp - z);
+        uu = p * (uu - e);
+        g = p * (g - d);
+      }
+      *reinterpret_cast<T*>(s + base + q * W) = sv;
+      *reinterpret_cast<T*>(gp + base + q * W) = gv;
+      *reinterpret_cast<T*>(u + base + q * W) = uv;
+      *reinterpret_cast<T*>(v + base + q * W) = vv;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -190,6 +243,14 @@ int tg_softmax_bwd(const float* gy, const float* y, float* gs, int rows, int col
 int tg_softmax_dbwd(const float* v, const float* gy, const float* y, float* out, int rows, int cols, void* stream) {
   TG_CHECK_PTR(v); TG_CHECK_PTR(gy); TG_CHECK_PTR(y); TG_CHECK_PTR(out); TG_CHECK_POS(rows); TG_CHECK_POS(cols);
   softmax_dbwd_kernel<<<row_grid(rows), RB, 0, tg_stream(stream)>>>(v, gy, y, out, rows, cols);
+  return tg_launch_status();
+}
+
+int tg_attn_dbwd_rows(float* s, const float* lse, float* gp, float* u, float* v, int rows, int cols, void* stream) {
+  TG_CHECK_PTR(s); TG_CHECK_PTR(lse); TG_CHECK_PTR(gp); TG_CHECK_PTR(u); TG_CHECK_PTR(v); TG_CHECK_POS(rows); TG_CHECK_POS(cols);
+  const bool vec = (cols % 4 == 0) && tg_aligned16(s) && tg_aligned16(gp) && tg_aligned16(u) && tg_aligned16(v);
+  if (vec) attn_dbwd_rows_kernel<true><<<row_grid(rows), RB, 0, tg_stream(stream)>>>(s, lse, gp, u, v, rows, cols);
+  else attn_dbwd_rows_kernel<false><<<row_grid(rows), RB, 0, tg_stream(stream)>>>(s, lse, gp, u, v, rows, cols);
   return tg_launch_status();
 }
 

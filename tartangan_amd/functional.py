@@ -1189,6 +1189,67 @@ def attention_composed(theta, phi, g):
     return matmul(g, beta, transB=True)                               # (B, DV, N)
 
 
+def _bgemm(A, Bm, ta=False, tb=False, out=None):
+    """out (+)= op(A) op(B), batched 3-D, no autograd (out given: accumulate into it)."""
+    batch, (ar, ac), (br, bc) = A.shape[0], A.shape[1:], Bm.shape[1:]
+    M, Kd = (ac, ar) if ta else (ar, ac)
+    N = br if tb else bc
+    beta = 1.0
+    if out is None:
+        out, beta = A.new_empty(batch, M, N), 0.0
+    K().gemm(A, Bm, out, None, M, N, Kd, ac, bc, N, int(ta), int(tb), batch, ar * ac, br * bc, M * N, beta)
+    return out
+
+
+class _AttnBwd(Function):
+    """(dtheta, dphi, dg) of the fused core, itself differentiable once more (what the R1 penalty asks of the
+    discriminator's real branch).  Forward: the fused first-order kernels.  Backward: the (N x M) maps by GEMM, one
+    row-wise kernel for the softmax algebra (tg_attn_dbwd_rows), GEMMs back down to the operand shapes."""
+
+    @staticmethod
+    def forward(ctx, go, theta, phi, g, o, lse):
+        go = go.contiguous()
+        B, D, N = theta.shape
+        DV, M = g.shape[1], g.shape[2]
+        dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
+        K().attn_bwd(go, theta, phi, g, o, lse, dtheta, dphi, dg, _ws(go, K().attn_bwd_workspace(B, D, DV, N, M)),
+                     B, D, DV, N, M)
+        ctx.save_for_backward(go, theta, phi, g, lse)
+        ctx.set_materialize_grads(False)
+        return dtheta, dphi, dg
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, a, b, c):
+        go, theta, phi, g, lse = ctx.saved_tensors
+        if a is None and b is None and c is None:
+            return None, None, None, None, None, None
+        B, D, N = theta.shape
+        M = g.shape[2]
+        a, b, c = (None if t is None else t.contiguous() for t in (a, b, c))
+        s = _bgemm(theta, phi, ta=True)                                   # (B, N, M) maps
+        gp = _bgemm(go, g, ta=True)
+        u = _bgemm(a, phi, ta=True) if a is not None else None
+        if b is not None:
+            u = _bgemm(theta, b, ta=True, out=u)
+        if u is None:
+            u = torch.zeros_like(s)
+        v = _bgemm(go, c, ta=True) if c is not None else torch.zeros_like(s)
+        K().attn_dbwd_rows(s, lse, gp, u, v, B * N, M)
+        p, gs, dgp, ds = s, gp, u, v
+        d_theta = _bgemm(phi, ds, tb=True)
+        if b is not None:
+            _bgemm(b, gs, tb=True, out=d_theta)
+        d_phi = _bgemm(theta, ds)
+        if a is not None:
+            _bgemm(a, gs, out=d_phi)
+        d_go = _bgemm(g, dgp, tb=True)
+        if c is not None:
+            _bgemm(c, p, tb=True, out=d_go)
+        d_g = _bgemm(go, dgp)
+        return d_go, d_theta, d_phi, d_g, None, None
+
+
 class _AttnCore(Function):
     @staticmethod
     def forward(ctx, theta, phi, g):
@@ -1204,21 +1265,8 @@ class _AttnCore(Function):
     @staticmethod
     def backward(ctx, go):
         theta, phi, g, o, lse = ctx.saved_tensors
-        if torch.is_grad_enabled():
-            # create_graph=True (R1 penalty on the real branch): the backward itself must be differentiable,
-            # so recompute through the composed primitives, which carry second-order kernels
-            inputs = [t for t, need in zip((theta, phi, g), ctx.needs_input_grad) if need]
-            with torch.enable_grad():
-                grads = torch.autograd.grad(attention_composed(theta, phi, g), inputs, go, create_graph=True)
-            it = iter(grads)
-            return tuple(next(it) if need else None for need in ctx.needs_input_grad)
-        go = go.contiguous()
-        B, D, N = theta.shape
-        DV, M = g.shape[1], g.shape[2]
-        dtheta, dphi, dg = torch.empty_like(theta), torch.empty_like(phi), torch.empty_like(g)
-        K().attn_bwd(go, theta, phi, g, o, lse, dtheta, dphi, dg, _ws(go, K().attn_bwd_workspace(B, D, DV, N, M)),
-                     B, D, DV, N, M)
-        return dtheta, dphi, dg
+        # under create_graph=True (R1 penalty on the real branch) this node lands in the graph and is differentiated again
+        return _AttnBwd.apply(go, theta, phi, g, o, lse)
 
 
 def attention_core(theta, phi, g):

@@ -411,6 +411,17 @@ class Emulator:
         dtheta.view(B, D, N).copy_(a); dphi.view(B, D, M).copy_(b); dg.view(B, DV, M).copy_(c)
         return 0
 
+    def attn_dbwd_rows(self, s, lse, gp, u, v, rows, cols):
+        S, G, U, V = _v(s, rows, cols), _v(gp, rows, cols), _v(u, rows, cols), _v(v, rows, cols)
+        P = torch.exp(S - lse.reshape(rows, 1))
+        d = (P * G).sum(-1, keepdim=True)
+        e = (P * U).sum(-1, keepdim=True)
+        dP = V + U * (G - d) - G * e
+        z = (P * dP).sum(-1, keepdim=True)
+        gS, dG, dS = P * (G - d), P * (U - e), P * (dP - z)
+        S.copy_(P); G.copy_(gS); U.copy_(dG); V.copy_(dS)
+        return 0
+
     # ---------------------------------------------------------------- iqn / losses
     def iqn_cos_embed(self, taus, rng, out, n, dims):
         out.copy_(torch.cos(taus.view(n, 1).repeat(1, dims) * math.pi * rng))

@@ -210,6 +210,28 @@ def test_stride2_functions_match_torch_including_double_backward(op):
             assert torch.allclose(a_, b_, rtol=2e-4, atol=2e-4), (op, second_order, float((a_ - b_).abs().max()))
 
 
+def test_attention_core_matches_torch_including_double_backward():
+    """The fused attention core under a gradient-norm penalty (its backward is differentiated again, as under R1):
+    the hand-derived second-order formulas against autograd on the textbook formulation."""
+    torch.manual_seed(5)
+    B, D, DV, N, M = 2, 4, 16, 24, 6
+    theta, phi, g = (torch.randn(B, d, n, requires_grad=True) for d, n in ((D, N), (D, M), (DV, M)))
+    ours = lambda: TF.attention_core(theta, phi, g)
+    ref = lambda: torch.bmm(g, torch.softmax(torch.bmm(theta.transpose(1, 2), phi), -1).transpose(1, 2))
+
+    def run(f, wrt):
+        for t in (theta, phi, g):
+            t.grad = None
+        y = f()
+        grads = torch.autograd.grad(y.tanh().sum(), wrt, create_graph=True)
+        (sum(q.pow(2).sum() for q in grads) + y.pow(2).sum()).backward()
+        return [y.detach()] + [t.grad.clone() for t in (theta, phi, g)]
+
+    for wrt in ((theta, phi, g), (theta,), (g,)):          # the last two leave some adjoints of the backward undefined
+        for a_, b_ in zip(run(ours, wrt), run(ref, wrt)):
+            assert torch.allclose(a_, b_, rtol=2e-4, atol=2e-5), float((a_ - b_).abs().max())
+
+
 def test_product_has_no_cpu_fallback():
     backend._set_backend_for_testing(None)
     x = torch.zeros(1, 4, 4, 4)

@@ -426,6 +426,34 @@ def test_fused_attention(K, dims):
                              ws, B, D, DV, N, M], [6, 7, 8], tol=2e-5)
 
 
+@pytest.mark.parametrize('shape', [(3 * 1024, 256), (2 * 300, 75), (70, 1024), (5, 6)])
+def test_attention_second_order_rows(K, shape):
+    """The row-wise middle of the differentiated attention backward; every output overwrites an input."""
+    rows, cols = shape
+    s, gp, u, v = (rnd(rows, cols, seed=i) for i in range(4))
+    lse = torch.logsumexp(s, -1)
+    run_both(K, 'attn_dbwd_rows', [s, lse, gp, u, v, rows, cols], [0, 2, 3, 4], tol=2e-5)
+
+
+@pytest.mark.parametrize('dims', [(3, 4, 16, 1024, 256), (2, 8, 32, 300, 75)])
+def test_attention_double_backward_matches_composed(K, dims):
+    """Gradient of a gradient-norm penalty through the fused core == the same through the twice-differentiable primitives."""
+    from tartangan_amd import functional as TF
+    B, D, DV, N, M = dims
+    theta, phi, g = (t.cuda().requires_grad_() for t in (rnd(B, D, N), rnd(B, D, M, seed=1), rnd(B, DV, M, seed=2)))
+
+    def run(f):
+        for t in (theta, phi, g):
+            t.grad = None
+        y = f(theta, phi, g)
+        grads = torch.autograd.grad(y.tanh().sum(), (theta, phi, g), create_graph=True)
+        (sum(q.pow(2).sum() for q in grads) + y.pow(2).sum()).backward()
+        return [y.detach()] + [t.grad.clone() for t in (theta, phi, g)]
+
+    for got, want in zip(run(TF.attention_core), run(TF.attention_composed)):
+        assert float((got - want).abs().max()) <= 1e-4 * max(float(want.abs().max()), 1e-3)
+
+
 def test_fused_attention_unsupported_dims(K):
     assert not K.attn_supported(3, 12)
     with pytest.raises(RuntimeError):
