@@ -248,6 +248,15 @@ int tg_attn_bwd(const float* go, const float* theta, const float* phi, const flo
  *   s <- P,  gp <- gS = P (gp - delta),  u <- dgP = P (u - eps),  v <- dS = P (dP - zeta),  dP = v + u (gp - delta) - gp eps
  * from which  d theta = phi dS^T + b gS^T,  d phi = theta dS + a gS,  d go = g dgP^T + c P^T,  d g = go dgP.          */
 int tg_attn_dbwd_rows(float* s, const float* lse, float* gp, float* u, float* v, int rows, int cols, void* stream);
+/* The same derivative in one kernel, no (N x M) map in memory, for key counts a wave can keep a whole row of in
+ * registers (M <= 256 at D + DV = 20; fewer for the wider heads): a (B,D,N), b (B,D,M), c (B,DV,M) are the adjoints of
+ * tg_attn_bwd's (dtheta, dphi, dg); d_go (B,DV,N), d_theta (B,D,N), d_phi (B,D,M), d_g (B,DV,M) the adjoints of its
+ * (go, theta, phi, g).  workspace: tg_attn_dbwd_workspace() bytes.  Otherwise TG_EUNSUPPORTED (compose as above). */
+int tg_attn_dbwd_supported(int D, int DV, int M);
+size_t tg_attn_dbwd_workspace(int B, int D, int DV, int N, int M);
+int tg_attn_dbwd(const float* go, const float* theta, const float* phi, const float* g, const float* lse,
+                 const float* a, const float* b, const float* c, float* d_go, float* d_theta, float* d_phi, float* d_g,
+                 float* workspace, int B, int D, int DV, int N, int M, void* stream);
 
 /* ---------------------------------------------------------------- IQN head (models/iqn.py)
  * out[i][j] = cos((taus[i] * pi) * range[j])   iqn.py:41-45 (fp32, this evaluation order) */

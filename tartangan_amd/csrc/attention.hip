@@ -447,6 +447,187 @@ int launch_bwd(const float* go, const float* theta, const float* phi, const floa
   return tg_launch_status();
 }
 
+// Wavefront sum on the DPP lanes of the vector ALU (no LDS crossbar round trips as with __shfl_xor): quad swaps, the two
+// row mirrors, then the row totals chained over rows 1..3; lane 63 holds the total, handed back wave-uniform.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define TG_DPP_ADD(CTRL, ROWS) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, false))
+  TG_DPP_ADD(0xB1, 0xf);      // quad_perm [1,0,3,2]
+  TG_DPP_ADD(0x4E, 0xf);      // quad_perm [2,3,0,1]
+  TG_DPP_ADD(0x141, 0xf);     // row_half_mirror
+  TG_DPP_ADD(0x140, 0xf);     // row_mirror: every lane of a 16-lane row has the row's sum
+  TG_DPP_ADD(0x142, 0xa);     // row_bcast15 into rows 1, 3
+  TG_DPP_ADD(0x143, 0xc);     // row_bcast31 into rows 2, 3
+#undef TG_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// =========================================================================== second order (R1 penalty)
+// The derivative of the first-order backward above: with (a, b, c) the adjoints of (dtheta, dphi, dg), the adjoints of
+// (go, theta, phi, g).  Per row n of the (N x M) maps (all of them functions of the row's and the columns' operands only):
+//   S = theta^T phi, P = exp(S - lse), gP = go^T g, U = a^T phi + theta^T b, V = go^T c,
+//   delta = sum P gP, eps = sum P U, zeta = sum P V + sum P U gP - 2 delta eps,
+//   gS = P (gP - delta), dgP = P (U - eps), dS = P (V + U (gP - delta) - gP eps - zeta),
+//   d theta[:, n] = phi dS + b gS,   d go[:, n] = g dgP + c P          (sums over the row)
+//   d phi += theta[:, n] dS + a[:, n] gS,   d g += go[:, n] dgP         (sums over rows)
+// Nothing N x M ever exists in memory: one wave owns 64 rows of one image; a lane owns CPL columns (m = lane + 64 j) and
+// keeps THEIR operands (phi, b, g, c: 2 (D + DV) CPL registers) and THEIR d phi / d g sums ((D + DV) CPL registers)
+// for its whole life; the row's operands are wave-uniform (scalar loads); row sums are wavefront reductions.  ~110 FMAs
+// per map element on the vector unit (the maps have tiny inner dimensions: MFMA would idle on operand shuffles here).
+template <int D, int DV, int CPL>
+__global__ void __launch_bounds__(64)
+attn_dbwd_kernel(const float* __restrict__ go, const float* __restrict__ theta, const float* __restrict__ phi, const float* __restrict__ g_,
+                 const float* __restrict__ lse, const float* __restrict__ a, const float* __restrict__ b_, const float* __restrict__ c_,
+                 float* __restrict__ d_go, float* __restrict__ d_theta, float* __restrict__ pphi, float* __restrict__ pg,
+                 int N, int M, int B) {
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x, bi = blockIdx.y;
+  const int n0 = w * 64;
+  const float* th = theta + (int64_t)bi * D * N;
+  const float* ab = a + (int64_t)bi * D * N;
+  const float* gob = go + (int64_t)bi * DV * N;
+  const float* lb = lse + (int64_t)bi * N;
+  float cphi[D][CPL], cb[D][CPL], cg[DV][CPL], cc[DV][CPL], sphi[D][CPL], sg[DV][CPL];
+  bool valid[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int m = lane + 64 * j;
+    valid[j] = m < M;
+    const int mm = valid[j] ? m : 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      cphi[k][j] = valid[j] ? phi[((int64_t)bi * D + k) * M + mm] : 0.f;
+      cb[k][j] = valid[j] ? b_[((int64_t)bi * D + k) * M + mm] : 0.f;
+      sphi[k][j] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < DV; ++q) {
+      cg[q][j] = valid[j] ? g_[((int64_t)bi * DV + q) * M + mm] : 0.f;
+      cc[q][j] = valid[j] ? c_[((int64_t)bi * DV + q) * M + mm] : 0.f;
+      sg[q][j] = 0.f;
+    }
+  }
+  float o_th[D], o_go[DV];               // lane i keeps the row outputs of row n0 + i
+#pragma unroll
+  for (int k = 0; k < D; ++k) o_th[k] = 0.f;
+#pragma unroll
+  for (int q = 0; q < DV; ++q) o_go[q] = 0.f;
+
+  const int nrows = min(64, N - n0);
+  for (int i = 0; i < nrows; ++i) {
+    const int n = n0 + i;
+    float rt[D], ra[D], rg[DV];          // wave-uniform row operands
+#pragma unroll
+    for (int k = 0; k < D; ++k) { rt[k] = th[k * N + n]; ra[k] = ab[k * N + n]; }
+#pragma unroll
+    for (int q = 0; q < DV; ++q) rg[q] = gob[q * N + n];
+    const float l = lb[n];
+    float P[CPL], GP[CPL], U[CPL], V[CPL];
+    float d = 0.f, e = 0.f, pv = 0.f, pug = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      float sv = 0.f, uv = 0.f, gv = 0.f, vv = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        sv = fmaf(rt[k], cphi[k][j], sv);
+        uv = fmaf(ra[k], cphi[k][j], uv);
+        uv = fmaf(rt[k], cb[k][j], uv);
+      }
+#pragma unroll
+      for (int q = 0; q < DV; ++q) {
+        gv = fmaf(rg[q], cg[q][j], gv);
+        vv = fmaf(rg[q], cc[q][j], vv);
+      }
+      const float p = valid[j] ? __expf(sv - l) : 0.f;
+      P[j] = p; GP[j] = gv; U[j] = uv; V[j] = vv;
+      d = fmaf(p, gv, d); e = fmaf(p, uv, e); pv = fmaf(p, vv, pv); pug = fmaf(p * uv, gv, pug);
+    }
+    d = wave_sum_dpp(d); e = wave_sum_dpp(e); pv = wave_sum_dpp(pv); pug = wave_sum_dpp(pug);
+    const float z = pv + pug - 2.f * d * e;
+    float GS[CPL], DS[CPL], DG[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const float dp = V[j] + U[j] * (GP[j] - d) - GP[j] * e;
+      GS[j] = P[j] * (GP[j] - d);
+      DS[j] = P[j] * (dp - z);
+      DG[j] = P[j] * (U[j] - e);
+    }
+    // row outputs
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      float r = 0.f;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) { r = fmaf(DS[j], cphi[k][j], r); r = fmaf(GS[j], cb[k][j], r); }
+      r = wave_sum_dpp(r);
+      o_th[k] = (lane == i) ? r : o_th[k];
+    }
+#pragma unroll
+    for (int q = 0; q < DV; ++q) {
+      float r = 0.f;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) { r = fmaf(DG[j], cg[q][j], r); r = fmaf(P[j], cc[q][j], r); }
+      r = wave_sum_dpp(r);
+      o_go[q] = (lane == i) ? r : o_go[q];
+    }
+    // column sums
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) { sphi[k][j] = fmaf(DS[j], rt[k], sphi[k][j]); sphi[k][j] = fmaf(GS[j], ra[k], sphi[k][j]); }
+#pragma unroll
+      for (int q = 0; q < DV; ++q) sg[q][j] = fmaf(DG[j], rg[q], sg[q][j]);
+    }
+  }
+  if (lane < nrows) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) d_theta[((int64_t)bi * D + k) * N + n0 + lane] = o_th[k];
+#pragma unroll
+    for (int q = 0; q < DV; ++q) d_go[((int64_t)bi * DV + q) * N + n0 + lane] = o_go[q];
+  }
+  // partial column sums [row slice w][B][D or DV][M], added in a fixed order by attn_reduce_k_kernel
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int m = lane + 64 * j;
+    if (m < M) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) pphi[(((int64_t)w * B + bi) * D + k) * M + m] = sphi[k][j];
+#pragma unroll
+      for (int q = 0; q < DV; ++q) pg[(((int64_t)w * B + bi) * DV + q) * M + m] = sg[q][j];
+    }
+  }
+}
+
+// columns per lane the register file takes: 3 (D + DV) CPL operand / sum registers next to the row's own
+static inline int dbwd_cpl(int D, int DV, int M) {
+  const int cpl = (M + 63) / 64;
+  return (cpl <= 4 && 3 * (D + DV) * cpl <= 256) ? cpl : 0;
+}
+
+template <int D, int DV, int CPL>
+int launch_dbwd(const float* go, const float* theta, const float* phi, const float* g, const float* lse, const float* a,
+                const float* b, const float* c, float* d_go, float* d_theta, float* d_phi, float* d_g, float* ws,
+                int B, int N, int M, hipStream_t st) {
+  const int S = (N + 63) / 64;
+  float* pphi = ws;
+  float* pg = ws + (int64_t)S * B * D * M;
+  attn_dbwd_kernel<D, DV, CPL><<<dim3(S, B), 64, 0, st>>>(go, theta, phi, g, lse, a, b, c, d_go, d_theta, pphi, pg, N, M, B);
+  const int64_t n1 = (int64_t)B * D * M, n2 = (int64_t)B * DV * M;
+  attn_reduce_k_kernel<<<tg_ew_grid(n1, AT), AT, 0, st>>>(pphi, d_phi, n1, S);
+  attn_reduce_k_kernel<<<tg_ew_grid(n2, AT), AT, 0, st>>>(pg, d_g, n2, S);
+  return tg_launch_status();
+}
+template <int D, int DV>
+int launch_dbwd_cpl(int cpl, const float* go, const float* theta, const float* phi, const float* g, const float* lse, const float* a,
+                    const float* b, const float* c, float* d_go, float* d_theta, float* d_phi, float* d_g, float* ws,
+                    int B, int N, int M, hipStream_t st) {
+  switch (cpl) {
+    case 1: return launch_dbwd<D, DV, 1>(go, theta, phi, g, lse, a, b, c, d_go, d_theta, d_phi, d_g, ws, B, N, M, st);
+    case 2: if constexpr (3 * (D + DV) * 2 <= 256) return launch_dbwd<D, DV, 2>(go, theta, phi, g, lse, a, b, c, d_go, d_theta, d_phi, d_g, ws, B, N, M, st); break;
+    case 3: if constexpr (3 * (D + DV) * 3 <= 256) return launch_dbwd<D, DV, 3>(go, theta, phi, g, lse, a, b, c, d_go, d_theta, d_phi, d_g, ws, B, N, M, st); break;
+    case 4: if constexpr (3 * (D + DV) * 4 <= 256) return launch_dbwd<D, DV, 4>(go, theta, phi, g, lse, a, b, c, d_go, d_theta, d_phi, d_g, ws, B, N, M, st); break;
+  }
+  return TG_EUNSUPPORTED;
+}
+
 }  // namespace
 
 #define TG_ATTN_DISPATCH(CALL)                   \
@@ -490,6 +671,33 @@ int tg_attn_bwd(const float* go, const float* theta, const float* phi, const flo
 #define CALL_BWD(d, v) launch_bwd<d, v>(go, theta, phi, g, o, lse, dtheta, dphi, dg, workspace, B, N, M, st)
   TG_ATTN_DISPATCH(CALL_BWD)
 #undef CALL_BWD
+}
+
+int tg_attn_dbwd_supported(int D, int DV, int M) {
+  return tg_attn_supported(D, DV) && M > 0 && dbwd_cpl(D, DV, M) > 0;
+}
+
+size_t tg_attn_dbwd_workspace(int B, int D, int DV, int N, int M) {
+  if (B <= 0 || D <= 0 || DV <= 0 || N <= 0 || M <= 0) return 0;
+  return (size_t)((N + 63) / 64) * B * (D + DV) * M * sizeof(float);
+}
+
+int tg_attn_dbwd(const float* go, const float* theta, const float* phi, const float* g, const float* lse, const float* a,
+                 const float* b, const float* c, float* d_go, float* d_theta, float* d_phi, float* d_g, float* workspace,
+                 int B, int D, int DV, int N, int M, void* stream) {
+  TG_CHECK_PTR(go); TG_CHECK_PTR(theta); TG_CHECK_PTR(phi); TG_CHECK_PTR(g); TG_CHECK_PTR(lse);
+  TG_CHECK_PTR(a); TG_CHECK_PTR(b); TG_CHECK_PTR(c);
+  TG_CHECK_PTR(d_go); TG_CHECK_PTR(d_theta); TG_CHECK_PTR(d_phi); TG_CHECK_PTR(d_g); TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(B); TG_CHECK_POS(N); TG_CHECK_POS(M);
+  if (!tg_attn_dbwd_supported(D, DV, M)) return TG_EUNSUPPORTED;
+  if (B > 65535) return TG_EINVAL;
+  const int cpl = dbwd_cpl(D, DV, M);
+  hipStream_t st = tg_stream(stream);
+#define TG_DBWD(D_, DV_) \
+  if (D == D_ && DV == DV_) return launch_dbwd_cpl<D_, DV_>(cpl, go, theta, phi, g, lse, a, b, c, d_go, d_theta, d_phi, d_g, workspace, B, N, M, st)
+  TG_DBWD(1, 4); TG_DBWD(2, 8); TG_DBWD(4, 16); TG_DBWD(8, 32); TG_DBWD(16, 64);
+#undef TG_DBWD
+  return TG_EUNSUPPORTED;
 }
 
 }  // extern "C"

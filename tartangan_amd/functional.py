@@ -1203,8 +1203,9 @@ def _bgemm(A, Bm, ta=False, tb=False, out=None):
 
 class _AttnBwd(Function):
     """(dtheta, dphi, dg) of the fused core, itself differentiable once more (what the R1 penalty asks of the
-    discriminator's real branch).  Forward: the fused first-order kernels.  Backward: the (N x M) maps by GEMM, one
-    row-wise kernel for the softmax algebra (tg_attn_dbwd_rows), GEMMs back down to the operand shapes."""
+    discriminator's real branch).  Forward: the fused first-order kernels.  Backward: one fused kernel (tg_attn_dbwd) when
+    a wave can hold a row of the map; else the (N x M) maps by GEMM, one row-wise kernel for the softmax algebra
+    (tg_attn_dbwd_rows) and GEMMs back down to the operand shapes."""
 
     @staticmethod
     def forward(ctx, go, theta, phi, g, o, lse):
@@ -1225,8 +1226,14 @@ class _AttnBwd(Function):
         if a is None and b is None and c is None:
             return None, None, None, None, None, None
         B, D, N = theta.shape
-        M = g.shape[2]
+        DV, M = g.shape[1], g.shape[2]
         a, b, c = (None if t is None else t.contiguous() for t in (a, b, c))
+        if K().attn_dbwd_supported(D, DV, M):                             # one kernel, the maps stay in registers
+            a, b, c = (torch.zeros_like(like) if t is None else t for t, like in ((a, theta), (b, phi), (c, g)))
+            d_go, d_theta, d_phi, d_g = (torch.empty_like(t) for t in (go, theta, phi, g))
+            K().attn_dbwd(go, theta, phi, g, lse, a, b, c, d_go, d_theta, d_phi, d_g,
+                          _ws(go, K().attn_dbwd_workspace(B, D, DV, N, M)), B, D, DV, N, M)
+            return d_go, d_theta, d_phi, d_g, None, None
         s = _bgemm(theta, phi, ta=True)                                   # (B, N, M) maps
         gp = _bgemm(go, g, ta=True)
         u = _bgemm(a, phi, ta=True) if a is not None else None

@@ -422,6 +422,25 @@ class Emulator:
         S.copy_(P); G.copy_(gS); U.copy_(dG); V.copy_(dS)
         return 0
 
+    def attn_dbwd_supported(self, D, DV, M):
+        cpl = (M + 63) // 64
+        return int(bool(self.attn_supported(D, DV)) and M > 0 and cpl <= 4 and 3 * (D + DV) * cpl <= 256)
+
+    def attn_dbwd_workspace(self, B, D, DV, N, M):
+        return 16
+
+    def attn_dbwd(self, go, theta, phi, g, lse, a, b, c, d_go, d_theta, d_phi, d_g, ws, B, D, DV, N, M):
+        assert self.attn_dbwd_supported(D, DV, M)
+        with torch.enable_grad():
+            gO, t, p, gg = (x.detach().clone().requires_grad_() for x in
+                            (go.view(B, DV, N), theta.view(B, D, N), phi.view(B, D, M), g.view(B, DV, M)))
+            out = torch.bmm(gg, F.softmax(torch.bmm(t.transpose(1, 2), p), -1).transpose(1, 2))
+            first = torch.autograd.grad(out, (t, p, gg), gO, create_graph=True)
+            second = torch.autograd.grad(first, (gO, t, p, gg), (a.view(B, D, N), b.view(B, D, M), c.view(B, DV, M)))
+        for dst, src in zip((d_go, d_theta, d_phi, d_g), second):
+            dst.view(src.shape).copy_(src)
+        return 0
+
     # ---------------------------------------------------------------- iqn / losses
     def iqn_cos_embed(self, taus, rng, out, n, dims):
         out.copy_(torch.cos(taus.view(n, 1).repeat(1, dims) * math.pi * rng))

@@ -435,7 +435,22 @@ def test_attention_second_order_rows(K, shape):
     run_both(K, 'attn_dbwd_rows', [s, lse, gp, u, v, rows, cols], [0, 2, 3, 4], tol=2e-5)
 
 
-@pytest.mark.parametrize('dims', [(3, 4, 16, 1024, 256), (2, 8, 32, 300, 75)])
+@pytest.mark.parametrize('dims', [(3, 4, 16, 1024, 256), (2, 8, 32, 300, 75), (2, 16, 64, 70, 17), (65, 4, 16, 1000, 250), (2, 1, 4, 200, 130),
+                                  (2, 2, 8, 64, 256)])
+def test_attention_second_order_fused(K, dims):
+    """Adjoints of (go, theta, phi, g) through the first-order backward, one kernel, against autograd of autograd."""
+    B, D, DV, N, M = dims
+    assert K.attn_dbwd_supported(D, DV, M)
+    assert not K.attn_dbwd_supported(D, DV, 64 * 4 + 1) and not K.attn_dbwd_supported(3, 12, M)
+    theta, phi, g, go = rnd(B, D, N), rnd(B, D, M, seed=1), rnd(B, DV, M, seed=2), rnd(B, DV, N, seed=3)
+    a, b, c = rnd(B, D, N, seed=4), rnd(B, D, M, seed=5), rnd(B, DV, M, seed=6)
+    lse = torch.logsumexp(torch.bmm(theta.transpose(1, 2), phi), -1)
+    ws = workspace(K.attn_dbwd_workspace(B, D, DV, N, M))
+    run_both(K, 'attn_dbwd', [go, theta, phi, g, lse, a, b, c, torch.zeros(B, DV, N), torch.zeros(B, D, N), torch.zeros(B, D, M),
+                              torch.zeros(B, DV, M), ws, B, D, DV, N, M], [8, 9, 10, 11], tol=3e-5)
+
+
+@pytest.mark.parametrize('dims', [(3, 4, 16, 1024, 256), (2, 8, 32, 300, 75), (1, 4, 16, 2048, 512)])
 def test_attention_double_backward_matches_composed(K, dims):
     """Gradient of a gradient-norm penalty through the fused core == the same through the twice-differentiable primitives."""
     from tartangan_amd import functional as TF
