@@ -38,8 +38,9 @@ struct RedStats {
   int C, HW;
   float pivot;
   __device__ void init(int c) { pivot = x[(int64_t)c * HW]; }   // first element of the channel: shift against cancellation
-  __device__ void acc4(int64_t off, float* a) {
-    const float4 v = *reinterpret_cast<const float4*>(x + off);
+  using V = float4;
+  __device__ V ld4(int64_t off) const { return *reinterpret_cast<const float4*>(x + off); }
+  __device__ void acc(const V& v, float* a) {
     const float d0 = v.x - pivot, d1 = v.y - pivot, d2 = v.z - pivot, d3 = v.w - pivot;
     a[0] += (d0 + d1) + (d2 + d3);
     a[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
@@ -142,8 +143,9 @@ struct FwdStatsBody {
       }
     }
   }
-  __device__ void vec4(int c, int64_t off) const {
-    const float4 v = *reinterpret_cast<const float4*>(x + off);
+  using V = float4;
+  __device__ V ld(int64_t off) const { return *reinterpret_cast<const float4*>(x + off); }
+  __device__ void st(int c, int64_t off, const V& v) const {
     float4 r;
     float y;
     y = bn_y(v.x, a, b); r.x = y >= 0.f ? y : y * slope;
@@ -171,10 +173,12 @@ struct RedBwd {
     acc[0] += gyh;
     acc[1] += gyh * ((xv - mu) * r);
   }
-  __device__ void acc4(int64_t off, float* acc) {
-    const float4 g = *reinterpret_cast<const float4*>(gz + off);
-    const float4 v = *reinterpret_cast<const float4*>(x + off);
-    elem(g.x, v.x, acc); elem(g.y, v.y, acc); elem(g.z, v.z, acc); elem(g.w, v.w, acc);
+  struct V { float4 g, v; };
+  __device__ V ld4(int64_t off) const {
+    return V{*reinterpret_cast<const float4*>(gz + off), *reinterpret_cast<const float4*>(x + off)};
+  }
+  __device__ void acc(const V& q, float* acc) {
+    elem(q.g.x, q.v.x, acc); elem(q.g.y, q.v.y, acc); elem(q.g.z, q.v.z, acc); elem(q.g.w, q.v.w, acc);
   }
   __device__ void acc1(int64_t off, float* acc) { elem(gz[off], x[off], acc); }
 };
@@ -244,11 +248,13 @@ struct BwdSumsBody {
     const float gyh = y >= 0.f ? g : g * slope;
     return training ? a * (gyh - k1 - ((xv - mu) * r) * k2) : a * gyh;
   }
-  __device__ void vec4(int c, int64_t off) const {
-    const float4 g = *reinterpret_cast<const float4*>(gz + off);
-    const float4 v = *reinterpret_cast<const float4*>(x + off);
+  struct V { float4 g, v; };
+  __device__ V ld(int64_t off) const {
+    return V{*reinterpret_cast<const float4*>(gz + off), *reinterpret_cast<const float4*>(x + off)};
+  }
+  __device__ void st(int c, int64_t off, const V& q) const {
     float4 o;
-    o.x = elem(g.x, v.x); o.y = elem(g.y, v.y); o.z = elem(g.z, v.z); o.w = elem(g.w, v.w);
+    o.x = elem(q.g.x, q.v.x); o.y = elem(q.g.y, q.v.y); o.z = elem(q.g.z, q.v.z); o.w = elem(q.g.w, q.v.w);
     *reinterpret_cast<float4*>(gx + off) = o;
   }
 };
@@ -270,11 +276,12 @@ struct RedDbwd {
     const float xh = (xv - mu) * r;
     acc[0] += vv; acc[1] += vv * xh; acc[2] += gyh; acc[3] += gyh * xh; acc[4] += vv * gyh;
   }
-  __device__ void acc4(int64_t off, float* acc) {
-    const float4 w = *reinterpret_cast<const float4*>(v + off);
-    const float4 g = *reinterpret_cast<const float4*>(gz + off);
-    const float4 q = *reinterpret_cast<const float4*>(x + off);
-    elem(w.x, g.x, q.x, acc); elem(w.y, g.y, q.y, acc); elem(w.z, g.z, q.z, acc); elem(w.w, g.w, q.w, acc);
+  struct V { float4 w, g, q; };
+  __device__ V ld4(int64_t off) const {
+    return V{*reinterpret_cast<const float4*>(v + off), *reinterpret_cast<const float4*>(gz + off), *reinterpret_cast<const float4*>(x + off)};
+  }
+  __device__ void acc(const V& t, float* acc) {
+    elem(t.w.x, t.g.x, t.q.x, acc); elem(t.w.y, t.g.y, t.q.y, acc); elem(t.w.z, t.g.z, t.q.z, acc); elem(t.w.w, t.g.w, t.q.w, acc);
   }
   __device__ void acc1(int64_t off, float* acc) { elem(v[off], gz[off], x[off], acc); }
 };

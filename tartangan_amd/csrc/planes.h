@@ -29,18 +29,38 @@ __global__ void __launch_bounds__(BLOCK) map_big(Body body, int C, int HW) {
 // reduction for ITS channel (`begin`: a wave-parallel sum of the S partials, a few hundred bytes from L2) instead
 // of a separate one-wave-per-channel kernel between the two passes.  `lead` marks the one block per channel that
 // also publishes the per-channel results (statistics, parameter gradients).
+// A block owns a CHANNEL and MAP_TILES tiles of it (over the images and the plane), so the channel prologue is paid once
+// per MAP_TILES x 4 KiB instead of once per 4 KiB, and the body is split into ld (all loads of the block's tiles are issued
+// before the first use: one load per thread in flight capped these passes near 4.5 TB/s) and st (compute + store).
+//   Body: typename V; V ld(int64_t off) const; void st(int c, int64_t off, const V&) const
+constexpr int MAP_TILES = 4;
 template <class Body>
-__global__ void __launch_bounds__(BLOCK) map_big_begin(Body body, int C, int HW) {
-  const int plane = blockIdx.x;
-  const int c = plane % C;
-  body.begin(c, plane == c && blockIdx.y == 0);
-  const int p = (blockIdx.y * BLOCK + threadIdx.x) * 4;
-  if (p < HW) body.vec4(c, (int64_t)plane * HW + p);
+__global__ void __launch_bounds__(BLOCK) map_big_begin(Body body, int B, int C, int HW) {
+  const int c = blockIdx.x;
+  body.begin(c, blockIdx.y == 0);
+  const int tiles_per_row = (HW + TILE - 1) / TILE;
+  const int T = B * tiles_per_row;
+  typename Body::V v[MAP_TILES];
+  int64_t off[MAP_TILES];
+  bool ok[MAP_TILES];
+#pragma unroll
+  for (int u = 0; u < MAP_TILES; ++u) {
+    const int t = blockIdx.y * MAP_TILES + u;
+    const int b = t / tiles_per_row;
+    const int p = (t - b * tiles_per_row) * TILE + threadIdx.x * 4;
+    ok[u] = t < T && p < HW;
+    off[u] = ((int64_t)b * C + c) * HW + p;
+    if (ok[u]) v[u] = body.ld(off[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < MAP_TILES; ++u)
+    if (ok[u]) body.st(c, off[u], v[u]);
 }
 template <class Body>
 static inline void launch_map_begin(Body body, int B, int C, int HW, hipStream_t st) {   // big regime only
-  dim3 grid(B * C, (HW + TILE - 1) / TILE);
-  map_big_begin<Body><<<grid, BLOCK, 0, st>>>(body, C, HW);
+  const int T = B * ((HW + TILE - 1) / TILE);
+  dim3 grid(C, (T + MAP_TILES - 1) / MAP_TILES);
+  map_big_begin<Body><<<grid, BLOCK, 0, st>>>(body, B, C, HW);
 }
 
 template <class Body>
@@ -77,7 +97,8 @@ static inline int splits(int B, int C, int HW) {
 
 // Red: static constexpr int K (values per element);
 //      __device__ void init(int c);
-//      __device__ void acc4(int64_t off, float* a /*K*/);   accumulate 4 elements
+//      typename V;  __device__ V ld4(int64_t off);          the loads of 4 elements
+//      __device__ void acc(const V&, float* a /*K*/);       accumulate them
 //      __device__ void acc1(int64_t off, float* a);
 // partial layout: [C][S][K] doubles.
 template <class Red>
@@ -92,10 +113,22 @@ __global__ void __launch_bounds__(BLOCK) reduce_stage1(Red red, double* __restri
   if (is_big) {
     const int tiles_per_row = (HW + TILE - 1) / TILE;
     const int T = B * tiles_per_row;
-    for (int t = s; t < T; t += S) {
-      const int b = t / tiles_per_row;
-      const int p = (t - b * tiles_per_row) * TILE + threadIdx.x * 4;
-      if (p < HW) red.acc4(((int64_t)b * C + c) * HW + p, a);
+    // four tiles per trip: their loads are all issued before the first sum (same summation order as one at a time)
+    constexpr int U = 4;
+    for (int t0 = s; t0 < T; t0 += U * S) {
+      typename Red::V v[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = t0 + u * S;
+        const int b = t / tiles_per_row;
+        const int p = (t - b * tiles_per_row) * TILE + threadIdx.x * 4;
+        ok[u] = t < T && p < HW;
+        if (ok[u]) v[u] = red.ld4(((int64_t)b * C + c) * HW + p);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[u]) red.acc(v[u], a);
     }
   } else {
     const int64_t n = (int64_t)B * HW;

@@ -21,10 +21,9 @@ struct RedChan {
   static constexpr int K = 1;
   const float* x;
   __device__ void init(int) {}
-  __device__ void acc4(int64_t off, float* a) {
-    const float4 v = *reinterpret_cast<const float4*>(x + off);
-    a[0] += (v.x + v.y) + (v.z + v.w);
-  }
+  using V = float4;
+  __device__ V ld4(int64_t off) const { return *reinterpret_cast<const float4*>(x + off); }
+  __device__ void acc(const V& v, float* a) { a[0] += (v.x + v.y) + (v.z + v.w); }
   __device__ void acc1(int64_t off, float* a) { a[0] += x[off]; }
 };
 
