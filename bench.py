@@ -101,7 +101,7 @@ class KernelTimer:
             setattr(self.K, name, fn)
 
     @staticmethod
-    def _empty_pair_ms(n=64):
+    def _empty_pair_ms(n=256):
         """Elapsed time between two events recorded back to back with nothing in between: the fixed cost that an
         event pair adds around a kernel; subtracted from every record (tiny kernels are otherwise over-counted)."""
         pairs = []
@@ -255,9 +255,15 @@ def main():
         saved = (getattr(tr, '_graphs', None), getattr(tr, '_graph_requested', False), tr.rng_feed.mode)
         tr._graphs, tr._graph_requested = None, False
         tr.rng_feed.mode = 'off'
+        timed_steps = 3                      # a few steps, averaged: one step's 196 conv launches are a noisy sample
         with KernelTimer(K) as kt:
-            tr.train_batch(imgs)
+            for _ in range(timed_steps):
+                tr.train_batch(imgs)
         agg = kt.summary()
+        for d in agg.values():               # per-step figures
+            for k in ('ms', 'flops', 'bytes'):
+                d[k] /= timed_steps
+            d['launches'] //= timed_steps
         tr._graphs, tr._graph_requested, tr.rng_feed.mode = saved
 
     if rank == 0:
