@@ -4,9 +4,9 @@ theta/phi/g/o are bias-free 1x1 convolutions, phi and g are 2x2 max-pooled, the
 (N x N/4) attention map is a row softmax of theta^T phi and the block returns
 gamma * o(g beta^T) + x with a learnable scalar gamma initialised to 0.
 
-The attention core runs in one fused kernel that never materialises the (N x N/4) map
-(forward and first-order backward).  Under the discriminator's R1 penalty the backward has to
-be differentiable itself; there it is recomputed from primitives that carry second-order kernels.
+The attention core runs in fused kernels that never materialise the (N x N/4) map: forward,
+first-order backward and -- under the discriminator's R1 penalty, where the backward is itself
+differentiated -- the hand-derived derivative of that backward (functional._AttnBwd).
 """
 import torch
 from torch import nn
