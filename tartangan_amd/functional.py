@@ -129,7 +129,12 @@ class _ConvDgrad(Function):
         if ctx.needs_input_grad[0]:
             a_gy = _ConvFwd.apply(v, w, None, None)
         if ctx.needs_input_grad[1]:
-            a_w = _ConvWgrad.apply(v, gy, w.shape[2])
+            # (the R1 penalty's contribution to the filter gradient) straight into .grad when it is a plain backward
+            sink = _grad_sink(w) if _param_grads_wanted() else None
+            if sink is not None:
+                _conv_wgrad_into(v, gy, sink, None, w.shape[2], accumulate=1)
+            else:
+                a_w = _ConvWgrad.apply(v, gy, w.shape[2])
         return a_gy, a_w
 
 
@@ -437,9 +442,12 @@ class _PoolConvT(Function):
             else:                                   # <v, PoolConvT(gy, w)> = <PoolConv(v, w), gy>: the pooled conv's weight gradient
                 B, Cout, H, W = gy.shape
                 Cin = w.shape[1]
-                a_w = torch.empty_like(w)
+                sink = _grad_sink(w)
                 ws = _ws(v, K().poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
-                K().poolconv3x3_wgrad(v, gy, a_w, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0)
+                if sink is None:
+                    a_w = torch.empty_like(w)
+                K().poolconv3x3_wgrad(v, gy, a_w if sink is None else sink, ws, ws.numel() * 4, B, Cin, Cout, H, W,
+                                      0 if sink is None else 1)
         return a_gy, a_w
 
 

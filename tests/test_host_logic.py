@@ -101,8 +101,9 @@ def test_flat_parameter_views_survive_load_state_dict():
 
 
 def test_deferred_wgrad_never_reduces_one_gradient_twice_in_a_launch():
-    """The batched reduce runs its items concurrently: the two contributions a discriminator weight collects in one
-    backward (real and fake batch) must land in different launches, and the result must equal the eager path."""
+    """The batched reduce runs its items concurrently: the contributions a discriminator weight collects in one backward
+    (real batch, fake batch, and the R1 penalty's second-order term) must land in different launches, and the result must
+    equal the eager path."""
     fx = load_golden('c32_cnn_b16')
 
     class Recording(Emulator):
@@ -117,7 +118,7 @@ def test_deferred_wgrad_never_reduces_one_gradient_twice_in_a_launch():
     imgs = synthetic_images(fx['batch'], 32, 7)
     torch.manual_seed(1)
     tr._d_phase(imgs)
-    assert len(Recording.calls) == 2
+    assert len(Recording.calls) == 3
     for t in Recording.calls:
         dst = t[:, 1].tolist()
         assert len(dst) == len(set(dst))
