@@ -355,11 +355,36 @@ def upconv3x3(a, weight, bias=None, residual=None):
     return _UpConv3x3.apply(a, weight, bias, residual)
 
 
+class _FilterForms:
+    """Derived filter layouts of the stride-2 forms, kept for the length of one ``filter_forms()`` scope."""
+    cache = None
+
+
+@contextlib.contextmanager
+def filter_forms():
+    """Scope in which the parameters do not change (one half of a training step: the discriminator is evaluated up to six
+    times between two of its optimiser steps): the 4x4 / four-phase layouts derived from a 3x3 filter are computed once
+    per scope instead of once per use.  Nothing outlives the scope, so nothing can go stale."""
+    outer, _FilterForms.cache = _FilterForms.cache, {}
+    try:
+        yield
+    finally:
+        _FilterForms.cache = outer
+
+
 def _poolconv_weights(x_like, w):
+    # an entry keeps its source tensor alive (its address cannot be handed to another tensor inside the scope) and is
+    # only valid for the version it was derived from
+    cache = _FilterForms.cache
+    key = (w.data_ptr(), tuple(w.shape))
+    if cache is not None and key in cache and cache[key][1] == w._version:
+        return cache[key][2], cache[key][3]
     Cout, Cin = w.shape[:2]
     w4 = x_like.new_empty(Cout, Cin, 4, 4)
     wp = x_like.new_empty(4, Cin, Cout, 2, 2)
     K().poolconv3x3_weights(w.contiguous(), w4, wp, Cout, Cin)
+    if cache is not None and w.is_contiguous():
+        cache[key] = (w, w._version, w4, wp)
     return w4, wp
 
 

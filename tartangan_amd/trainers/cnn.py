@@ -84,15 +84,16 @@ class CNNTrainer(Trainer):
         real = imgs.detach()
         if self.args.grad_penalty:
             real = real.requires_grad_()
-        p_real, d_loss = self._d_losses(real, fake.detach(), labels)
-        d_grad_penalty = None
-        if self.args.grad_penalty:
-            d_grad_penalty = TF.scale(gradient_penalty(p_real, real), self.args.grad_penalty)
-            d_loss = TF.add(d_loss, d_grad_penalty)
-        # same parameter gradients as d_loss.backward(); naming the leaves just spares autograd the gradient
-        # w.r.t. the real images, which the reference computes (real.requires_grad_) and never reads
-        with TF.deferred_wgrad():       # one launch finishes all conv weight-gradient reductions of this pass
-            torch.autograd.backward(d_loss, inputs=[p for p in self.d.parameters() if p.requires_grad])
+        with TF.filter_forms():         # the discriminator's parameters are fixed until its optimiser step
+            p_real, d_loss = self._d_losses(real, fake.detach(), labels)
+            d_grad_penalty = None
+            if self.args.grad_penalty:
+                d_grad_penalty = TF.scale(gradient_penalty(p_real, real), self.args.grad_penalty)
+                d_loss = TF.add(d_loss, d_grad_penalty)
+            # same parameter gradients as d_loss.backward(); naming the leaves just spares autograd the gradient
+            # w.r.t. the real images, which the reference computes (real.requires_grad_) and never reads
+            with TF.deferred_wgrad():       # one launch finishes all conv weight-gradient reductions of this pass
+                torch.autograd.backward(d_loss, inputs=[p for p in self.d.parameters() if p.requires_grad])
         return d_loss.detach(), (d_grad_penalty.detach() if d_grad_penalty is not None else None)
 
     def _g_phase(self, bs):
@@ -101,9 +102,10 @@ class CNNTrainer(Trainer):
         toggle_grad(self.d, False)
         self.optimizer_g.zero_grad()
         fake = self.sample_g(bs)
-        g_loss = self._g_loss(fake, torch.ones(bs, 1, device=self.device))
-        with TF.deferred_wgrad():
-            g_loss.backward()
+        with TF.filter_forms():
+            g_loss = self._g_loss(fake, torch.ones(bs, 1, device=self.device))
+            with TF.deferred_wgrad():
+                g_loss.backward()
         return g_loss.detach()
 
     def train_batch(self, imgs):
