@@ -233,6 +233,34 @@ def test_attention_core_matches_torch_including_double_backward():
             assert torch.allclose(a_, b_, rtol=2e-4, atol=2e-5), float((a_ - b_).abs().max())
 
 
+def test_filter_forms_scope_derives_each_filter_once_and_never_serves_a_stale_one():
+    calls = []
+
+    class Counting(Emulator):
+        def poolconv3x3_weights(self, w, w4, wp, Cout, Cin):
+            calls.append(w.data_ptr())
+            return super().poolconv3x3_weights(w, w4, wp, Cout, Cin)
+
+    backend._set_backend_for_testing(Counting())
+    torch.manual_seed(0)
+    x = torch.randn(2, 4, 16, 16)
+    w = torch.nn.Parameter(torch.randn(6, 4, 3, 3) * 0.2)
+    ref = lambda: torch.nn.functional.avg_pool2d(torch.nn.functional.conv2d(x, w, None, padding=1), 2)
+    TF.pool_conv3x3(x, w); TF.pool_conv3x3(x, w)
+    assert len(calls) == 2                                   # no scope: derived per use
+    with TF.filter_forms():
+        a = TF.pool_conv3x3(x, w)
+        b = TF.pool_conv3x3(x, w)
+        assert len(calls) == 3 and torch.equal(a, b)         # once per scope
+        with torch.no_grad():
+            w.mul_(2.0)                                      # an in-place update inside the scope: new version, new forms
+        c = TF.pool_conv3x3(x, w)
+        assert len(calls) == 4
+        assert torch.allclose(c, ref(), rtol=1e-4, atol=1e-5)
+    TF.pool_conv3x3(x, w)
+    assert len(calls) == 5                                   # nothing survives the scope
+
+
 def test_product_has_no_cpu_fallback():
     backend._set_backend_for_testing(None)
     x = torch.zeros(1, 4, 4, 4)
