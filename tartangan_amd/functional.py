@@ -501,8 +501,11 @@ class _Gemm(Function):
         assert Kd == Kb, (A.shape, Bm.shape, ta, tb)
         shape = (batch, M, N) if A.dim() == 3 else (M, N)
         C = A.new_empty(shape)
-        K().gemm(A, Bm, C, None, M, N, Kd, ac, bc, N, int(ta), int(tb), batch,
-                 ar * ac, br * bc, M * N, 0.0)
+        if A.dim() == 2 and ta and not tb:
+            _gemm_tn_into(A, Bm, C, accumulate=False)
+        else:
+            K().gemm(A, Bm, C, None, M, N, Kd, ac, bc, N, int(ta), int(tb), batch,
+                     ar * ac, br * bc, M * N, 0.0)
         ctx.save_for_backward(A, Bm)
         ctx.ta, ctx.tb = ta, tb
         return C
@@ -521,6 +524,31 @@ class _Gemm(Function):
 
 def matmul(A, Bm, transA=False, transB=False):
     return _Gemm.apply(A, Bm, transA, transB)
+
+
+def _gemm_tn_into(A, Bm, out, accumulate):
+    """out (+)= A^T B for 2-D A (rows x M), B (rows x N): the weight gradient of a Linear layer.  With many rows and a
+    small M x N (the IQN head sees quantiles x batch rows) a single launch is one or two workgroups walking the whole
+    reduction; there the rows are cut into slices that run as ONE batched GEMM, and the slices are summed."""
+    rows, M = A.shape
+    N = Bm.shape[1]
+    S = 1
+    if rows >= 2048 and M * N <= 256 * 256:
+        S = 64
+        while S > 1 and (rows % S or rows // S < 64):
+            S //= 2
+    if S == 1:
+        K().gemm(A, Bm, out, None, M, N, rows, M, N, N, 1, 0, 1, 0, 0, 0, 1.0 if accumulate else 0.0)
+        return
+    r = rows // S
+    part = A.new_empty(S, M, N)
+    K().gemm(A, Bm, part, None, M, N, r, M, N, N, 1, 0, S, r * M, r * N, M * N, 0.0)
+    if accumulate:
+        total = A.new_empty(M, N)
+        K().sum_reps(part, total, 1.0, M, N, S)
+        K().add(out, total, out, out.numel())
+    else:
+        K().sum_reps(part, out, 1.0, M, N, S)
 
 
 class _Linear(Function):
@@ -544,9 +572,7 @@ class _Linear(Function):
         if ctx.needs_input_grad[1] and _param_grads_wanted():
             sink = _grad_sink(w)
             if sink is not None:          # gw += gy^T x straight into the flat bucket
-                M, N = gy.shape
-                Kd = x.shape[1]
-                K().gemm(gy, x, sink, None, N, Kd, M, N, Kd, Kd, 1, 0, 1, 0, 0, 0, 1.0)
+                _gemm_tn_into(gy, x, sink, accumulate=True)
             else:
                 gw = _Gemm.apply(gy, x, True, False)
         if bias is not None and ctx.needs_input_grad[2] and _param_grads_wanted():

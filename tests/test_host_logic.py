@@ -261,6 +261,20 @@ def test_filter_forms_scope_derives_each_filter_once_and_never_serves_a_stale_on
     assert len(calls) == 5                                   # nothing survives the scope
 
 
+def test_tall_linear_weight_gradient_is_row_sliced_and_equals_torch():
+    """quantiles x batch rows into a small Linear (the IQN head): the weight gradient runs as one batched GEMM over row
+    slices + a sum; same numbers as the plain product, with and without an existing .grad to accumulate into."""
+    torch.manual_seed(2)
+    x = torch.randn(4096, 48)
+    lin = torch.nn.Linear(48, 24)
+    w, b = torch.nn.Parameter(lin.weight.detach().clone()), torch.nn.Parameter(lin.bias.detach().clone())
+    for _ in range(2):                              # second pass: .grad exists -> accumulate-in-place path
+        TF.linear(x, w, b).tanh().sum().backward()
+        torch.nn.functional.linear(x, lin.weight, lin.bias).tanh().sum().backward()
+        assert torch.allclose(w.grad, lin.weight.grad, rtol=1e-4, atol=1e-4)
+        assert torch.allclose(b.grad, lin.bias.grad, rtol=1e-4, atol=1e-4)
+
+
 def test_product_has_no_cpu_fallback():
     backend._set_backend_for_testing(None)
     x = torch.zeros(1, 4, 4, 4)
