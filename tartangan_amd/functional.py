@@ -528,14 +528,15 @@ def matmul(A, Bm, transA=False, transB=False):
 
 def _gemm_tn_into(A, Bm, out, accumulate):
     """out (+)= A^T B for 2-D A (rows x M), B (rows x N): the weight gradient of a Linear layer.  With many rows and a
-    small M x N (the IQN head sees quantiles x batch rows) a single launch is one or two workgroups walking the whole
-    reduction; there the rows are cut into slices that run as ONE batched GEMM, and the slices are summed."""
+    small M x N (the IQN head: 8 quantiles x 64 images into 20 -> 128 and 128 -> 1 layers) a single launch is one or two
+    workgroups walking the whole reduction, one dependent global load per 16 rows (86-98 us for 512 rows); there the rows
+    are cut into slices that run as ONE batched GEMM, and the slices are summed."""
     rows, M = A.shape
     N = Bm.shape[1]
     S = 1
-    if rows >= 2048 and M * N <= 256 * 256:
+    if rows >= 256 and M * N <= 256 * 256:      # (one k-step of the GEMM kernel is 16 rows)
         S = 64
-        while S > 1 and (rows % S or rows // S < 64):
+        while S > 1 and (rows % S or rows // S < 16):
             S //= 2
     if S == 1:
         K().gemm(A, Bm, out, None, M, N, rows, M, N, N, 1, 0, 1, 0, 0, 0, 1.0 if accumulate else 0.0)

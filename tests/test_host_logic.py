@@ -265,7 +265,7 @@ def test_tall_linear_weight_gradient_is_row_sliced_and_equals_torch():
     """quantiles x batch rows into a small Linear (the IQN head): the weight gradient runs as one batched GEMM over row
     slices + a sum; same numbers as the plain product, with and without an existing .grad to accumulate into."""
     torch.manual_seed(2)
-    x = torch.randn(4096, 48)
+    x = torch.randn(512, 48)
     lin = torch.nn.Linear(48, 24)
     w, b = torch.nn.Parameter(lin.weight.detach().clone()), torch.nn.Parameter(lin.bias.detach().clone())
     for _ in range(2):                              # second pass: .grad exists -> accumulate-in-place path
