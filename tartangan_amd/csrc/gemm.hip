@@ -26,28 +26,37 @@ __global__ void __launch_bounds__(GT) gemm_kernel(const float* __restrict__ A, c
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    // stage A tile (BM x BK) and B tile (BK x BN); choose the thread->element map so that the
-    // fastest-varying thread index follows the contiguous memory dimension
+  // The next k-tile's global loads are issued before this tile's products (register prefetch): with one load -> LDS ->
+  // barrier -> products round trip per 16 k-values, the small-grid products of the step (a Linear layer on 64..512 rows:
+  // one to 32 workgroups) spent ~2.7 us per k-tile waiting on memory.
+  // Thread -> element map: the fastest-varying thread index follows the contiguous memory dimension.
+  constexpr int PER = BM * BK / GT;
+  static_assert(BM == BN && PER * GT == BM * BK, "square tiles, whole elements per thread");
+  float ra[PER], rb[PER];
+  auto load = [&](int k0) {
 #pragma unroll
-    for (int e = tid; e < BM * BK; e += GT) {
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * GT;
       int m, k;
       if (TA) { m = e % BM; k = e / BM; } else { k = e % BK; m = e / BK; }
       const int gm = m0 + m, gk = k0 + k;
-      float v = 0.f;
-      if (gm < M && gk < K) v = TA ? A[(int64_t)gk * lda + gm] : A[(int64_t)gm * lda + gk];
-      As[k][m] = v;
+      ra[u] = (gm < M && gk < K) ? (TA ? A[(int64_t)gk * lda + gm] : A[(int64_t)gm * lda + gk]) : 0.f;
+      int n, kb;
+      if (TB) { kb = e % BK; n = e / BK; } else { n = e % BN; kb = e / BN; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      rb[u] = (gn < N && gkb < K) ? (TB ? Bm[(int64_t)gn * ldb + gkb] : Bm[(int64_t)gkb * ldb + gn]) : 0.f;
     }
+  };
+  load(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
 #pragma unroll
-    for (int e = tid; e < BK * BN; e += GT) {
-      int n, k;
-      if (TB) { k = e % BK; n = e / BK; } else { n = e % BN; k = e / BN; }
-      const int gn = n0 + n, gk = k0 + k;
-      float v = 0.f;
-      if (gn < N && gk < K) v = TB ? Bm[(int64_t)gn * ldb + gk] : Bm[(int64_t)gk * ldb + gn];
-      Bs[k][n] = v;
+    for (int u = 0; u < PER; ++u) {
+      const int e = tid + u * GT;
+      if (TA) As[e / BM][e % BM] = ra[u]; else As[e % BK][e / BK] = ra[u];
+      if (TB) Bs[e % BK][e / BK] = rb[u]; else Bs[e / BN][e % BN] = rb[u];
     }
     __syncthreads();
+    if (k0 + BK < K) load(k0 + BK);
 #pragma unroll
     for (int k = 0; k < BK; ++k) {
       const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
