@@ -113,12 +113,24 @@ class KernelTimer:
         vals = sorted(a.elapsed_time(b) for a, b in pairs)
         return vals[len(vals) // 2]
 
-    def summary(self):
+    def summary(self, steps=1):
+        """Per-STEP totals.  `steps` identical steps were recorded back to back: launch i of every step is the same kernel
+        on the same shapes, and its time is the MEDIAN over the steps -- in an eager pass the GPU sometimes runs ahead of
+        the host, and the wait for the next launch packet then lands between the two events of that launch."""
         torch.cuda.synchronize()
         base = self._empty_pair_ms()
+        per = len(self.records) // steps
+        same = steps > 1 and per * steps == len(self.records) and all(
+            self.records[i][0] == self.records[i + k * per][0] for k in range(1, steps) for i in range(per))
+        times = [max(a.elapsed_time(b) - base, 0.0) for _, _, a, b in self.records]
+        if same:
+            times = [sorted(times[i + k * per] for k in range(steps))[steps // 2] for i in range(per)]
+            records = self.records[:per]
+        else:
+            times = [t / steps for t in times]
+            records = self.records
         agg = {}
-        for name, args, a, b in self.records:
-            ms = max(a.elapsed_time(b) - base, 0.0)
+        for (name, args, _, _), ms in zip(records, times):
             flops = 0.0
             nbytes = 0.0
             if name in CONV_DIMS:
@@ -140,6 +152,11 @@ class KernelTimer:
             d['launches'] += 1
             d['flops'] += flops
             d['bytes'] += nbytes
+        if not same and steps > 1:                # steps differed in their launch sequence: plain per-step averages
+            for d in agg.values():
+                d['launches'] //= steps
+                d['flops'] /= steps
+                d['bytes'] /= steps
         return agg
 
 
@@ -255,15 +272,11 @@ def main():
         saved = (getattr(tr, '_graphs', None), getattr(tr, '_graph_requested', False), tr.rng_feed.mode)
         tr._graphs, tr._graph_requested = None, False
         tr.rng_feed.mode = 'off'
-        timed_steps = 3                      # a few steps, averaged: one step's 196 conv launches are a noisy sample
+        timed_steps = 3                      # a few steps: one step's 196 conv launches are a noisy sample
         with KernelTimer(K) as kt:
             for _ in range(timed_steps):
                 tr.train_batch(imgs)
-        agg = kt.summary()
-        for d in agg.values():               # per-step figures
-            for k in ('ms', 'flops', 'bytes'):
-                d[k] /= timed_steps
-            d['launches'] //= timed_steps
+        agg = kt.summary(timed_steps)
         tr._graphs, tr._graph_requested, tr.rng_feed.mode = saved
 
     if rank == 0:
