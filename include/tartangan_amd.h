@@ -218,6 +218,11 @@ int tg_lrelu_bwd(const float* g, const float* x, float slope, float* out, int64_
 int tg_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
 /* out = g * (1 - y*y) */
 int tg_tanh_bwd(const float* g, const float* y, float* out, int64_t n, void* stream);
+/* nn.ELU / nn.SELU (trainers/cnn.py:42-44 --activation elu|selu): y = x > 0 ? scale*x : scale*alpha*(exp(x)-1) */
+int tg_elu_fwd(const float* x, float alpha, float scale, float* y, int64_t n, void* stream);
+/* order 1: out = g * f'(x) (elu_backward); order 2: out = g * f''(x) (elu_double_backward, the R1 real branch) */
+int tg_elu_bwd(const float* g, const float* x, float alpha, float scale, int order, float* out, int64_t n,
+               void* stream);
 int tg_fill(float* x, float value, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------- softmax (attention.py:32) */

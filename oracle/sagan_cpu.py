@@ -48,8 +48,35 @@ NUM_QUANTILES = 8      # models/iqn.py:78
 QUANTILE_DIMS = 20     # models/iqn.py:78
 
 
-def get_config(name, attention=None):
-    cfg = CONFIGS[name]
+# option variants of the trainers (trainers/cnn.py:32-45): --norm bn|id, --activation relu|selu|elu, --g-base mlp|tiledz.
+# Module-level switches set by OracleTrainer (the oracle is single-threaded test code).
+class Options:
+    norm = 'bn'
+    activation = 'relu'
+    g_base = 'mlp'
+
+
+def act(x):
+    """activation_factory() of trainers/cnn.py:41-45"""
+    if Options.activation == 'relu':
+        return F.leaky_relu(x, SLOPE)
+    if Options.activation == 'selu':
+        return F.selu(x)
+    if Options.activation == 'elu':
+        return F.elu(x)
+    raise KeyError(Options.activation)
+
+
+def get_config(name, attention=None, blocks=None, latent_dims=None, base_size=None):
+    """A named config, or (fixtures of configs this table does not hold / scaled models) explicit widths."""
+    if name in CONFIGS:
+        cfg = CONFIGS[name]
+    else:
+        cfg = GANConfig(base_size or 4, latent_dims, 3, tuple(blocks), ())
+    if blocks is not None:
+        cfg = cfg._replace(blocks=tuple(blocks))          # GANConfig.scale_model (models/pluggan.py:24-28)
+    if latent_dims is not None:
+        cfg = cfg._replace(latent_dims=latent_dims)
     if attention is not None:
         cfg = cfg._replace(attention=tuple(attention))
     return cfg
@@ -65,6 +92,8 @@ def _conv_t(S, key, cout, cin, k, bias=True):
 
 
 def _bn_t(S, key, c):
+    if Options.norm == 'id':          # nn.Identity: no parameters, no buffers
+        return
     S[key + '.weight'] = torch.ones(c)
     S[key + '.bias'] = torch.zeros(c)
     S[key + '.running_mean'] = torch.zeros(c)
@@ -83,8 +112,9 @@ def _attn_t(S, key, c):
 def g_template(cfg):
     S = OrderedDict()
     c0 = cfg.blocks[0]
-    S['blocks.0.base_img.0.weight'] = torch.zeros(cfg.base_size ** 2 * c0, cfg.latent_dims)
-    S['blocks.0.base_img.0.bias'] = torch.zeros(cfg.base_size ** 2 * c0)
+    if Options.g_base == 'mlp':       # TiledZGeneratorInput (generator.py:101-112) has no parameters
+        S['blocks.0.base_img.0.weight'] = torch.zeros(cfg.base_size ** 2 * c0, cfg.latent_dims)
+        S['blocks.0.base_img.0.bias'] = torch.zeros(cfg.base_size ** 2 * c0)
     bi, cin = 1, c0
     for i, cout in enumerate(cfg.blocks):
         p = f'blocks.{bi}'
@@ -190,6 +220,8 @@ def default_init_(S, seed_continue=True):
 # layers
 # --------------------------------------------------------------------------
 def _bn(S, key, x, training):
+    if Options.norm == 'id':
+        return x
     if training:
         S[key + '.num_batches_tracked'] += 1
     return F.batch_norm(x, S[key + '.running_mean'], S[key + '.running_var'],
@@ -203,11 +235,11 @@ def _conv(S, key, x, pad):
 def _res_convs(S, p, x, first, training):
     if first:
         h = _conv(S, p + '.convs.0', x, 1)
-        h = F.leaky_relu(_bn(S, p + '.convs.1', h, training), SLOPE)
+        h = act(_bn(S, p + '.convs.1', h, training))
         return _conv(S, p + '.convs.3', h, 1)
-    h = F.leaky_relu(_bn(S, p + '.convs.0', x, training), SLOPE)
+    h = act(_bn(S, p + '.convs.0', x, training))
     h = _conv(S, p + '.convs.2', h, 1)
-    h = F.leaky_relu(_bn(S, p + '.convs.3', h, training), SLOPE)
+    h = act(_bn(S, p + '.convs.3', h, training))
     return _conv(S, p + '.convs.5', h, 1)
 
 
@@ -229,8 +261,11 @@ def self_attention(S, p, x):
 
 def g_forward(S, z, cfg, training=True):
     c0 = cfg.blocks[0]
-    x = F.leaky_relu(F.linear(z, S['blocks.0.base_img.0.weight'], S['blocks.0.base_img.0.bias']), SLOPE)
-    x = x.view(-1, c0, cfg.base_size, cfg.base_size)
+    if Options.g_base == 'tiledz':    # generator.py:110-112
+        x = z[..., None, None].repeat(1, 1, cfg.base_size, cfg.base_size)
+    else:
+        x = act(F.linear(z, S['blocks.0.base_img.0.weight'], S['blocks.0.base_img.0.bias']))
+        x = x.view(-1, c0, cfg.base_size, cfg.base_size)
     bi, cin = 1, c0
     for i, cout in enumerate(cfg.blocks):
         p = f'blocks.{bi}'
@@ -245,7 +280,7 @@ def g_forward(S, z, cfg, training=True):
             bi += 1
         cin = cout
     p = f'blocks.{bi}'
-    x = F.leaky_relu(_bn(S, p + '.convs.0', x, training), SLOPE)
+    x = act(_bn(S, p + '.convs.0', x, training))
     return torch.tanh(_conv(S, p + '.convs.2', x, 0))
 
 
@@ -275,7 +310,7 @@ def _d_trunk(S, x, cfg, iqn, training):
 def d_forward(S, x, cfg, training=True):
     x, bi = _d_trunk(S, x, cfg, False, training)
     p = f'blocks.{bi}'
-    x = F.leaky_relu(_bn(S, p + '.activation.0', x, training), SLOPE)
+    x = act(_bn(S, p + '.activation.0', x, training))
     x = torch.sum(x, [2, 3])
     return F.linear(x, S[p + '.to_output.0.weight'], S[p + '.to_output.0.bias'])
 
@@ -309,7 +344,7 @@ def iqn_loss(preds, target, taus, k=1.):
 def iqn_d_forward(S, x, cfg, targets=None, training=True, taus=None):
     x, _ = _d_trunk(S, x, cfg, True, training)
     p = 'to_output'
-    feats = F.leaky_relu(_bn(S, p + '.activation.0', x, training), SLOPE)
+    feats = act(_bn(S, p + '.activation.0', x, training))
     feats = torch.sum(feats, [2, 3])
     batch = feats.shape[0]
     feats_rep = feats.repeat(NUM_QUANTILES, 1)
@@ -342,8 +377,13 @@ class OracleTrainer:
     """trainers/cnn.py:29-165 and trainers/iqn.py:29-156 restated on state dicts."""
 
     def __init__(self, config, kind='cnn', batch_size=64, attention=None, lr_g=1e-4, lr_d=4e-4,
-                 lr_target_g=1e-3, grad_penalty=5., device='cpu'):
-        self.cfg = get_config(config, attention) if isinstance(config, str) else config
+                 lr_target_g=1e-3, grad_penalty=5., device='cpu', norm='bn', activation='relu', g_base='mlp',
+                 model_scale=1., blocks=None, latent_dims=None):
+        Options.norm, Options.activation, Options.g_base = norm, activation, g_base
+        if kind == 'iqn' and activation == 'elu':
+            raise KeyError(activation)                   # trainers/iqn.py:41-44 has no 'elu'
+        self.cfg = get_config(config, attention, blocks, latent_dims) if isinstance(config, str) else config
+        self.cfg = self.cfg._replace(blocks=tuple(int(c * model_scale) for c in self.cfg.blocks))
         self.kind = kind
         self.batch_size = batch_size
         self.lr_target_g = lr_target_g
@@ -354,7 +394,20 @@ class OracleTrainer:
         self.target_g = default_init_(g_template(self.cfg))
         self.d = default_init_(d_template(self.cfg, iqn=(kind == 'iqn')))
         self._make_optimizers(lr_g, lr_d)
+        if activation == 'selu':                 # cnn.py:92-94
+            self._init_params_selu(self.g)
+            self._init_params_selu(self.d)
         self.update_target_generator()       # cnn.py:95 (lr argument is ignored there)
+
+    def _init_params_selu(self, S):
+        """cnn.py:97-105: vectors zeroed, everything else N(0, 1/fan_in), in .parameters() order."""
+        with torch.no_grad():
+            for p in self._params(S):
+                if p.dim() == 1:
+                    p.zero_()
+                else:
+                    fan_in, _ = torch.nn.init._calculate_fan_in_and_fan_out(p)
+                    p.normal_(std=float(np.sqrt(1. / fan_in)))
 
     def _params(self, S):
         return [v for k, v in S.items() if is_param(k)]

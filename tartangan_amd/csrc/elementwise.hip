@@ -19,6 +19,15 @@ struct OpLreluBwd {   // a = g, b = x
 struct OpTanhBwd {    // a = g, b = y
   __device__ float operator()(float g, float y) const { return g * (1.f - y * y); }
 };
+// ELU family (nn.ELU: alpha 1, scale 1; nn.SELU: alpha 1.6732632..., scale 1.0507009...), ATen's elu / elu_backward /
+// elu_double_backward with input_scale 1: the negative branch is taken for x <= 0.
+struct OpEluBwd {     // a = g, b = x; order 1: g f'(x), order 2: g f''(x)
+  float negcoef, poscoef; int order;
+  __device__ float operator()(float g, float x) const {
+    if (x <= 0.f) return g * negcoef * expf(x);
+    return order == 1 ? g * poscoef : 0.f;
+  }
+};
 struct OpScaleAdd {   // s*a + b
   const float* s;
   __device__ float operator()(float a, float b) const { return (*s) * a + b; }
@@ -51,6 +60,10 @@ struct OpScaleDev {
   __device__ float operator()(float x) const { return (alpha * (*s)) * x; }
 };
 struct OpTanh { __device__ float operator()(float x) const { return tanhf(x); } };
+struct OpElu {
+  float negcoef, poscoef;
+  __device__ float operator()(float x) const { return x <= 0.f ? expm1f(x) * negcoef : x * poscoef; }
+};
 struct OpFill { float v; __device__ float operator()(float) const { return v; } };
 
 template <class Op, bool READ>
@@ -235,6 +248,13 @@ int tg_scale_dev(const float* s, float alpha, const float* x, float* out, int64_
   return launch_unary<OpScaleDev, true>(x, out, n, stream, OpScaleDev{s, alpha});
 }
 int tg_tanh_fwd(const float* x, float* y, int64_t n, void* stream) { return launch_unary<OpTanh, true>(x, y, n, stream, OpTanh{}); }
+int tg_elu_fwd(const float* x, float alpha, float scale, float* y, int64_t n, void* stream) {
+  return launch_unary<OpElu, true>(x, y, n, stream, OpElu{alpha * scale, scale});
+}
+int tg_elu_bwd(const float* g, const float* x, float alpha, float scale, int order, float* out, int64_t n, void* stream) {
+  if (order != 1 && order != 2) return TG_EINVAL;
+  return launch_binary(g, x, out, n, stream, OpEluBwd{alpha * scale, scale, order});
+}
 int tg_fill(float* x, float value, int64_t n, void* stream) { return launch_unary<OpFill, false>(nullptr, x, n, stream, OpFill{value}); }
 
 size_t tg_reduce_workspace(int64_t n) { (void)n; return (size_t)RED_MAX_BLOCKS * sizeof(double); }

@@ -1148,6 +1148,60 @@ def leaky_relu(x, slope=0.2):
     return _LRelu.apply(x, float(slope))
 
 
+# nn.ELU / nn.SELU (reference trainers/cnn.py:42-44).  SELU = ELU with ATen's constants (torch.selu calls
+# at::elu(x, alpha, scale)).
+SELU_ALPHA = 1.6732632423543772848170429916717
+SELU_SCALE = 1.0507009873554804934193349852946
+
+
+class _Elu(Function):
+    @staticmethod
+    def forward(ctx, x, alpha, scale):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        K().elu_fwd(x, alpha, scale, y, x.numel())
+        ctx.save_for_backward(x)
+        ctx.alpha, ctx.scale = alpha, scale
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return _EluBwd.apply(g, x, ctx.alpha, ctx.scale, 1), None, None
+
+
+class _EluBwd(Function):
+    """order 1: g f'(x) (differentiable once more: the R1 real branch); order 2: g f''(x)."""
+
+    @staticmethod
+    def forward(ctx, g, x, alpha, scale, order):
+        g, x = g.contiguous(), x.contiguous()
+        out = torch.empty_like(x)
+        K().elu_bwd(g, x, alpha, scale, order, out, x.numel())
+        ctx.save_for_backward(g, x)
+        ctx.alpha, ctx.scale, ctx.order = alpha, scale, order
+        return out
+
+    @staticmethod
+    def backward(ctx, v):
+        g, x = ctx.saved_tensors
+        a_g = _EluBwd.apply(v, x, ctx.alpha, ctx.scale, ctx.order) if ctx.needs_input_grad[0] else None
+        a_x = None
+        if ctx.needs_input_grad[1]:
+            if ctx.order != 1:
+                raise NotImplementedError('third-order ELU derivative')
+            a_x = _Mul.apply(v, _EluBwd.apply(g, x, ctx.alpha, ctx.scale, 2))
+        return a_g, a_x, None, None, None
+
+
+def elu(x, alpha=1.0):
+    return _Elu.apply(x, float(alpha), 1.0)
+
+
+def selu(x):
+    return _Elu.apply(x, SELU_ALPHA, SELU_SCALE)
+
+
 class _Tanh(Function):
     @staticmethod
     def forward(ctx, x):

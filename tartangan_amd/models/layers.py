@@ -65,6 +65,16 @@ class LeakyReLU(nn.LeakyReLU):
         return TF.leaky_relu(x, self.negative_slope)
 
 
+class ELU(nn.ELU):
+    def forward(self, x):
+        return TF.elu(x, self.alpha)
+
+
+class SELU(nn.SELU):
+    def forward(self, x):
+        return TF.selu(x)
+
+
 class Tanh(nn.Tanh):
     def forward(self, x):
         return TF.tanh(x)

@@ -9,6 +9,7 @@ consumption order, BatchNorm mode and label layout.
 """
 import functools
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -17,7 +18,7 @@ from ..models.blocks import (
     DiscriminatorOutput, GeneratorInputMLP, GeneratorOutput, ResidualDiscriminatorBlock,
     ResidualGeneratorBlock, TiledZGeneratorInput,
 )
-from ..models.layers import BatchNorm2d, LeakyReLU
+from ..models.layers import ELU, SELU, BatchNorm2d, LeakyReLU
 from ..models.losses import gradient_penalty
 from ..models.pluggan import GAN_CONFIGS, Discriminator, Generator
 from ..optim import FusedAdam, ema_update
@@ -28,12 +29,14 @@ from .utils import toggle_grad
 class CNNTrainer(Trainer):
     discriminator_class = Discriminator
     d_output_class = DiscriminatorOutput
+    # --activation (cnn.py:41-45); an unknown name is a KeyError, as in the reference
+    activations = {'relu': functools.partial(LeakyReLU, 0.2), 'selu': SELU, 'elu': ELU}
 
     # ------------------------------------------------------------------ model assembly
     def _factories(self):
         norm = {'id': nn.Identity, 'bn': BatchNorm2d}[self.args.norm]
         g_input = {'mlp': GeneratorInputMLP, 'tiledz': TiledZGeneratorInput}[self.args.g_base]
-        act = {'relu': functools.partial(LeakyReLU, 0.2)}[self.args.activation]
+        act = self.activations[self.args.activation]
         bind = functools.partial
         return dict(
             g_input=bind(g_input, activation_factory=act),
@@ -59,7 +62,23 @@ class CNNTrainer(Trainer):
                                           output_factory=f['d_output']).to(self.device)
         self.optimizer_g = FusedAdam(self.g, lr=self.args.lr_g, betas=(0., 0.999))
         self.optimizer_d = FusedAdam(self.d, lr=self.args.lr_d, betas=(0., 0.999))
+        if self.args.activation == 'selu':
+            self.init_params_selu(self.g.parameters())
+            self.init_params_selu(self.d.parameters())
         self.update_target_generator(1.)     # the reference's "copy weights" (see below)
+
+    @torch.no_grad()
+    def init_params_selu(self, params):
+        """cnn.py:97-105 / iqn.py:94-102: vectors zeroed, matrices and filters N(0, 1/fan_in).  Drawn from the CPU
+        default generator in parameter order (what the reference does on its CPU device), then moved, so that a seed
+        gives the same initial weights on any device.  A 0-d parameter (the attention gamma) raises ValueError from
+        ``_calculate_fan_in_and_fan_out``, exactly as the reference does for --activation selu with attention."""
+        for p in params:
+            if p.dim() == 1:
+                p.zero_()
+            else:
+                fan_in, _ = nn.init._calculate_fan_in_and_fan_out(p)
+                p.copy_(torch.empty(p.shape).normal_(std=float(np.sqrt(1. / fan_in))))
 
     # ------------------------------------------------------------------ the step
     def _d_losses(self, real, fake, labels):

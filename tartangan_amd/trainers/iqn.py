@@ -14,6 +14,7 @@ from .cnn import CNNTrainer
 class IQNTrainer(CNNTrainer):
     discriminator_class = IQNDiscriminator
     d_output_class = IQNDiscriminatorOutput
+    activations = {k: v for k, v in CNNTrainer.activations.items() if k != 'elu'}      # iqn.py:41-44 has no 'elu'
 
     def _d_losses(self, real, fake, labels):
         bs = len(real)

@@ -32,3 +32,18 @@ def single_thread():
     torch.set_num_threads(1)
     yield
     torch.set_num_threads(n)
+
+
+def trainer_from_fixture(fx, device, seed=0):
+    """The HIP-engine trainer a fixture describes (config, attention, trainer kind, batch and the option flags
+    make_golden.py passed to the reference trainer), built from ``seed`` like the reference was."""
+    import torch
+    from tartangan_amd.models.pluggan import GAN_CONFIGS
+    from tartangan_amd.trainers.cnn import CNNTrainer
+    from tartangan_amd.trainers.iqn import IQNTrainer
+    cls = {'cnn': CNNTrainer, 'iqn': IQNTrainer}[fx['trainer']]
+    cfg = GAN_CONFIGS[fx['config']]._replace(attention=tuple(fx['attention']))
+    tr = cls(cls.default_args(config=cfg, batch_size=fx['batch'], device=device, **fx.get('flags', {})))
+    torch.manual_seed(seed)
+    tr.build_models()
+    return tr

@@ -361,6 +361,16 @@ class Emulator:
         out.copy_(torch.where(x >= 0, g, g * slope))
         return 0
 
+    def elu_fwd(self, x, alpha, scale, y, n):
+        y.copy_(scale * F.elu(x, alpha))
+        return 0
+
+    def elu_bwd(self, g, x, alpha, scale, order, out, n):
+        neg = g * (alpha * scale) * torch.exp(x)
+        pos = g * scale if order == 1 else torch.zeros_like(g)
+        out.copy_(torch.where(x <= 0, neg, pos))
+        return 0
+
     def tanh_fwd(self, x, y, n):
         y.copy_(torch.tanh(x))
         return 0

@@ -96,6 +96,18 @@ CASES = {
     'c128a3_iqn_b4': ('128:3', 'iqn', 4, 2),
     'c64a1_cnn_b64': ('64:1', 'cnn', 64, 1),
     'c64a1_iqn_b64': ('64:1', 'iqn', 64, 1),
+    # the benched workload and the per-rank batches of BASELINE.json configs 4 / 5
+    'c128a3_cnn_b64': ('128:3', 'cnn', 64, 1),
+    'c128a3_cnn_b32': ('128:3', 'cnn', 32, 1),
+    'c128a3_iqn_b64': ('128:3', 'iqn', 64, 1),
+    # option variants: trainer flags as a 5th element
+    'c32_cnn_b8_selu': ('32', 'cnn', 8, 2, dict(activation='selu')),
+    'c32_cnn_b8_elu': ('32', 'cnn', 8, 2, dict(activation='elu')),
+    'c32_iqn_b8_selu': ('32', 'iqn', 8, 2, dict(activation='selu')),
+    'c32_cnn_b8_tiledz': ('32', 'cnn', 8, 2, dict(g_base='tiledz')),
+    'c64a1_cnn_b4_scale075': ('64:1', 'cnn', 4, 2, dict(model_scale=0.75)),
+    'c32_cnn_b8_id': ('32', 'cnn', 8, 2, dict(norm='id')),
+    'c512thin_test_cnn_b2': ('512thin-test', 'cnn', 2, 1),
 }
 
 WEIGHT_SEED = 7
@@ -103,18 +115,22 @@ RNG_SEED = 1234
 IMG_SEED = 4321
 
 
-def make_args(config, batch):
-    return argparse.Namespace(
+def make_args(config, batch, **flags):
+    ns = argparse.Namespace(
         config=config, model_scale=1., norm='bn', g_base='mlp', activation='relu',
         lr_g=1e-4, lr_d=4e-4, lr_target_g=1e-3, batch_size=batch,
         grad_penalty=5., device='cpu', run_id='golden', output='/tmp/golden_out',
     )
+    for k, v in flags.items():
+        assert hasattr(ns, k), k
+        setattr(ns, k, v)
+    return ns
 
 
-def build_trainer(config, kind, batch, init_seed=0):
+def build_trainer(config, kind, batch, init_seed=0, **flags):
     cls = {'cnn': CNNTrainer, 'iqn': IQNTrainer}[kind]
     t = object.__new__(cls)          # skip Trainer.__init__ (filesystem side effects only)
-    t.args = make_args(config, batch)
+    t.args = make_args(config, batch, **flags)
     torch.manual_seed(init_seed)
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):   # build_models prints the nets
@@ -143,16 +159,18 @@ def total_l2(module, grads=False):
 
 
 def run_case(name):
-    config, kind, batch, steps = CASES[name]
+    config, kind, batch, steps = CASES[name][:4]
+    flags = CASES[name][4] if len(CASES[name]) > 4 else {}
     t0 = time.time()
-    tr = build_trainer(config, kind, batch)
+    tr = build_trainer(config, kind, batch, **flags)
     size = tr.g.max_size
     fixture = dict(
-        case=name, config=config.split(':')[0],
+        case=name, config=config.split(':')[0], flags=flags,
         attention=list(GAN_CONFIGS[config].attention), trainer=kind, batch=batch,
         size=size, weight_seed=WEIGHT_SEED, rng_seed=RNG_SEED, img_seed=IMG_SEED,
         torch_version=torch.__version__, num_threads=torch.get_num_threads(),
         source='reference tartangan v0.4.0 code under torch %s CPU fp32' % torch.__version__,
+        blocks=list(tr.gan_config.blocks), latent_dims=tr.gan_config.latent_dims,     # after --model-scale
     )
     # default-init pin (same seed -> same initial parameters, incl. the
     # lr-ignoring update_target_generator(1.) quirk, cnn.py:95,158-165)

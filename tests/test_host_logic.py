@@ -8,7 +8,7 @@ pin everything between the C ABI and the reference's Python API."""
 import pytest
 import torch
 
-from conftest import golden_cases, load_golden
+from conftest import golden_cases, load_golden, trainer_from_fixture
 from emulator import Emulator
 from oracle import sagan_cpu as O
 from oracle.procedural import procedural_state, summarize, synthetic_images
@@ -30,13 +30,7 @@ def _close(a, b, rel=1e-4, abs_=1e-6):
 
 
 def make_trainer(fx, seed=0):
-    cls = {'cnn': CNNTrainer, 'iqn': IQNTrainer}[fx['trainer']]
-    cfg = GAN_CONFIGS[fx['config']]._replace(attention=tuple(fx['attention']))
-    args = cls.default_args(config=cfg, batch_size=fx['batch'], device='cpu')
-    tr = cls(args)
-    torch.manual_seed(seed)
-    tr.build_models()
-    return tr
+    return trainer_from_fixture(fx, 'cpu', seed)
 
 
 def _total_l2(module, grads=False):

@@ -10,8 +10,24 @@ from conftest import golden_cases, load_golden
 from oracle import sagan_cpu as O
 from oracle.procedural import procedural_state, summarize, synthetic_images
 
-FAST = [c for c in golden_cases() if not c.endswith('b64')]
-SLOW = [c for c in golden_cases() if c.endswith('b64')]
+import os
+
+# Cases the single-threaded oracle finishes in seconds run by default.  The full-batch ones (64:1 at batch 64: ~1 min each;
+# 128:3 at batch 32 / 64: 1-4 min each) are the same check and run with TG_SLOW_ORACLE=1 (done in the build container
+# whenever the oracle or a fixture changes); the GPU suite compares the HIP trainers with those fixtures directly.
+def _is_slow(c):
+    return c.endswith('b64') or c.endswith('b32') or c.startswith('c512')
+
+
+FAST = [c for c in golden_cases() if not _is_slow(c)]
+SLOW = [c for c in golden_cases() if _is_slow(c)]
+
+
+def oracle_from_fixture(fx):
+    flags = dict(fx.get('flags', {}))
+    flags.pop('model_scale', None)                    # fx['blocks'] holds the widths after --model-scale
+    return O.OracleTrainer(fx['config'], fx['trainer'], fx['batch'], attention=fx['attention'],
+                           blocks=fx.get('blocks'), latent_dims=fx.get('latent_dims'), **flags)
 
 
 def _close(a, b, rel=2e-5, abs_=1e-7):
@@ -40,7 +56,7 @@ def _total_l2(S, grads=False):
 def _run(case):
     fx = load_golden(case)
     torch.manual_seed(0)
-    tr = O.OracleTrainer(fx['config'], fx['trainer'], fx['batch'], attention=fx['attention'])
+    tr = oracle_from_fixture(fx)
     # state_dict key parity with the reference modules
     assert list(tr.g.keys()) == fx['state_keys']['g']
     assert list(tr.d.keys()) == fx['state_keys']['d']
@@ -109,6 +125,7 @@ def test_oracle_matches_reference_fixture(case, single_thread):
 
 
 @pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get('TG_SLOW_ORACLE'), reason='minutes of single-threaded CPU; set TG_SLOW_ORACLE=1')
 @pytest.mark.parametrize('case', SLOW)
 def test_oracle_matches_reference_fixture_full_batch(case, single_thread):
     _run(case)

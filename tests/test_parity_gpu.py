@@ -7,7 +7,7 @@ when its CPU thread count changes (DESIGN.md "Chaotic divergence")."""
 import pytest
 import torch
 
-from conftest import golden_cases, load_golden
+from conftest import golden_cases, load_golden, trainer_from_fixture
 from oracle.procedural import procedural_state, summarize, synthetic_images
 
 pytestmark = pytest.mark.gpu
@@ -33,15 +33,7 @@ def _close(a, b, rel, abs_=1e-6):
 
 
 def make_trainer(fx):
-    from tartangan_amd.models.pluggan import GAN_CONFIGS
-    from tartangan_amd.trainers.cnn import CNNTrainer
-    from tartangan_amd.trainers.iqn import IQNTrainer
-    cls = {'cnn': CNNTrainer, 'iqn': IQNTrainer}[fx['trainer']]
-    cfg = GAN_CONFIGS[fx['config']]._replace(attention=tuple(fx['attention']))
-    tr = cls(cls.default_args(config=cfg, batch_size=fx['batch'], device='cuda'))
-    torch.manual_seed(0)
-    tr.build_models()
-    return tr
+    return trainer_from_fixture(fx, 'cuda')
 
 
 def _total_l2(module, grads=False):
