@@ -19,6 +19,7 @@
 // Pixel tiles:
 //   256 pixels, waves split pixels : G4 (16 4x4 images) G8 (4 8x8) G16 (one 16x16) GX (8 rows x 32)
 //    64 pixels, waves split K       : G4k G8k G16k  -- small-spatial layers still fill the chip
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -33,7 +34,8 @@ constexpr int CT_THREADS = 256;
 template <int TH_, int TW_, int NI_>
 struct Geo {
   static constexpr int TH = TH_, TW = TW_, NI = NI_, NPIX = TH_ * TW_ * NI_;
-  static_assert(NPIX == 256 || NPIX == 64, "a pixel tile is 256 pixels (waves split pixels) or 64 (waves split K)");
+  static_assert(NPIX == 512 || NPIX == 256 || NPIX == 64, "a pixel tile is 512 / 256 pixels (waves split pixels) or 64 (waves split K)");
+  static constexpr int PPW = (NPIX == 64) ? 64 : NPIX / 4;     // pixels per wave
   static_assert(TW_ % 4 == 0, "rows are staged as float4");
 };
 using G4 = Geo<4, 4, 16>;
@@ -43,6 +45,8 @@ using GX = Geo<8, 32, 1>;
 using G4k = Geo<4, 4, 4>;
 using G8k = Geo<8, 8, 1>;
 using G16k = Geo<4, 16, 1>;
+using GX2 = Geo<16, 32, 1>;     // 512-pixel tiles of the LDS-DMA kernel (conv_dma_kernel)
+using G16x2 = Geo<16, 16, 2>;
 
 // Kernel-size codes: 1 = 1x1; 3 = 3x3 pad 1; 2 = a 2x2 window of taps INSIDE the 3x3 halo (one output phase of
 // conv3x3(nearest_up2x(.)), see tg_upconv3x3_*): patch geometry of the 3x3 kernel, 4 taps starting at (oy, ox).
@@ -293,7 +297,7 @@ struct FwdCore {
   static constexpr int CT = MF * MT;
   using WT = WTile<KS, CT, WK>;
   static constexpr int KK = WT::KK, CK = WT::CK, CTS = WT::CTS;
-  static constexpr int NT = 64 / MF;                 // pixel sub-tiles per wave (64 pixels per wave)
+  static constexpr int NT = G::PPW / MF;             // pixel sub-tiles per wave
   static constexpr int KG = (MF == 32) ? 2 : 4;      // k values consumed per MFMA
   static constexpr int NREG = (MF == 32) ? 16 : 4;
   static constexpr int NG = CK / KG;                 // k-groups per chunk
@@ -463,6 +467,201 @@ conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
 
   if constexpr (WK) {
     // sum the four waves' partial accumulators through LDS (fixed order)
+    __syncthreads();
+    float* red = lds;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) red[(((wave * MT + m) * NT + n) * NREG + r) * 64 + lane] = acc[m][n][r];
+    __syncthreads();
+    constexpr int PW_ = MT * NT * NREG * 64;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          const int e = ((m * NT + n) * NREG + r) * 64 + lane;
+          acc[m][n][r] = (red[e] + red[PW_ + e]) + (red[2 * PW_ + e] + red[3 * PW_ + e]);
+        }
+  }
+  Core::epilogue(acc, bias, residual, y, s, tc, co0, pix0, j, h, wave);
+}
+
+// =========================================================================== 3x3 forward / dgrad, LDS-DMA staged
+// Same implicit GEMM as conv_fwd_kernel, but the patch and the filter slice go global -> LDS directly
+// (buffer_load_dwordx4 ... lds: 1 KiB per wave-instruction, no VGPR staging, no ds_write, no per-element address
+// or bounds arithmetic in the loop) into TWO buffers, one barrier per channel chunk:
+//     DMA(chunk 0);  for c: { vmcnt(0); barrier; DMA(chunk c + 1 -> other buffer); MFMA(chunk c) }
+// What makes the LDS images lane-linear (an LDS-DMA writes base + lane * 16, not a scatter):
+//   * patch rows are staged as WHOLE 16-byte chunks, four columns beyond the tile on either side (the halo column is
+//     the last / first float of those chunks): a row is (TW + 8) / 4 chunks, a channel PH rows, channels back to back
+//     (+ pad chunks so that the channel stride is 16 mod 32 banks);
+//   * everything outside the image, beyond the batch or in a pad chunk is a lane whose buffer offset is out of range:
+//     the buffer bounds check returns zeros for it and touches no memory -- zero padding costs nothing;
+//   * the filter slice is copied as it lies in memory, [rows][row length] with the fragment reads indexing it
+//     (forward: rows = output channels, (ci, tap) along the row; dgrad: rows = the gy channels of the chunk,
+//     (output channel, tap) along the row, taps read flipped) -- no transposing store.
+// Per-lane buffer offsets are computed once per tile; a chunk step moves the (wave-uniform) descriptor base.
+// Preconditions (host): W % 4 == 0, 16-byte aligned x / w, channel counts % 4 == 0, tensors < 2 GiB.
+template <class G> struct DPatch {
+  static constexpr int PH = G::TH + 2, PWS = G::TW + 8, QR = PWS / 4;
+  static constexpr int IMG = PH * PWS, RAW = G::NI * IMG;
+  static constexpr int CIS = RAW + ((48 - RAW % 32) % 32);       // channel stride, == 16 (mod 32)
+  static constexpr int CPC = CIS / 4;                            // 16-byte chunks per channel (pad chunks included)
+  static_assert(CIS % 32 == 16 && CIS % 4 == 0, "channel stride");
+  __device__ __forceinline__ static int pix(int p) {             // LDS offset (inside a channel) of pixel p's top-left tap
+    const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
+    return (img * PH + rem / G::TW) * PWS + rem % G::TW + 3;
+  }
+};
+template <int CT, int CK, bool DGRAD> struct DFilt {
+  static constexpr int ROWS = DGRAD ? CK : CT;
+  static constexpr int ROWLEN = (DGRAD ? CT : CK) * 9;
+  static constexpr int RS = ROWLEN + 4;                          // + one pad chunk: rows do not all start on one bank
+  static constexpr int QW = RS / 4;
+  static constexpr int SIZE = ROWS * RS;
+};
+constexpr uint32_t DMA_OOB = 0x80000000u;                        // >= any descriptor's num_records (tensors < 2 GiB)
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_wave_base, uint32_t voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+template <class G, int MF, int MT, int CK, bool DGRAD>
+__global__ void __launch_bounds__(CT_THREADS)
+conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                const float* __restrict__ residual, float* __restrict__ y, Shape s, int xcd_swizzle) {
+  using P = DPatch<G>;
+  constexpr int CT = MF * MT;
+  using F = DFilt<CT, CK, DGRAD>;
+  constexpr bool WK = (G::NPIX == 64);            // 64-pixel tiles: the waves share the pixels and split the k-groups of a chunk
+  using Core = FwdCore<G, 3, MF, MT, WK>;
+  constexpr int NT = Core::NT, KG = Core::KG, NG = CK / KG, NREG = Core::NREG;
+  static_assert(!WK || NG % 4 == 0, "K-split needs a multiple of 4 k-groups per chunk");
+  constexpr int PCH = CK * P::CPC, WCH = F::ROWS * F::QW;        // chunks per buffer: patch, filter
+  constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVW = (WCH + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCH * 4, WBUF = WCH * 4;                  // floats; lanes past the last chunk of a region issue no DMA
+  constexpr int BUF = PBUF + WBUF;
+  constexpr int REDF = WK ? 4 * MT * NT * NREG * 64 : 0;         // cross-wave reduction of the K-split partial sums
+  __shared__ __attribute__((aligned(16))) float lds[(2 * BUF > REDF) ? 2 * BUF : REDF];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % MF, h = lane / MF;
+  int bid = blockIdx.x;
+  if (xcd_swizzle) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);     // an XCD (block id mod 8) works on neighbouring tiles
+  const TileCoord tc = decode_tile<G>(bid, s.H, s.W);
+  const int co0 = blockIdx.y * CT;
+  const int pix0 = WK ? 0 : wave * G::PPW;
+  const int g0 = WK ? wave : 0;                                  // WK: wave w takes k-groups w, w + 4, ...
+  const uint32_t HW = (uint32_t)(s.H * s.W);
+
+  // ---- per-lane buffer offsets (bytes), fixed for the whole tile
+  uint32_t poff[NVP], woff[NVW];
+#pragma unroll
+  for (int i = 0; i < NVP; ++i) {
+    const int e = i * CT_THREADS + threadIdx.x;
+    const int ci = e / P::CPC, rem = e % P::CPC;
+    const int row = rem / P::QR, q = rem % P::QR;
+    const int img = row / P::PH, r = row % P::PH;
+    const int hh = tc.h0 + r - 1, ww = tc.w0 - 4 + 4 * q;
+    const bool ok = (e < PCH) && (rem < P::RAW / 4) && (tc.b0 + img < s.B) && (hh >= 0) && (hh < s.H) && (ww >= 0) && (ww < s.W);
+    poff[i] = ok ? (__umul24(__umul24(img, s.Cin) + ci, HW) + __umul24(hh, s.W) + ww) << 2 : DMA_OOB;
+  }
+  // filter: forward rows = output channels co0.., row = w[co][ci0 .. ci0+CK][9]; dgrad rows = the chunk's gy channels,
+  // row = w[kc][co0 .. co0+CT][9] (w is the forward filter [s.Cin (gy channels)][s.Cout (gx channels)][9])
+  const int row_floats = (DGRAD ? s.Cout : s.Cin) * 9;           // floats per row of w as stored
+#pragma unroll
+  for (int i = 0; i < NVW; ++i) {
+    const int e = i * CT_THREADS + threadIdx.x;
+    const int row = e / F::QW, q = e % F::QW;
+    bool ok = (e < WCH) && (4 * q < F::ROWLEN);
+    if (DGRAD) ok = ok && (4 * q < (s.Cout - co0) * 9);          // (columns past the last output channel)
+    else ok = ok && (co0 + row < s.Cout);
+    woff[i] = ok ? (uint32_t)(row * row_floats + 4 * q) << 2 : DMA_OOB;
+  }
+
+  // ---- wave-uniform descriptor bases; a chunk step advances them
+  const char* xb = reinterpret_cast<const char*>(x) + ((int64_t)tc.b0 * s.Cin * HW) * 4;
+  int64_t xbytes = (int64_t)(s.B - tc.b0) * s.Cin * HW * 4;
+  const int64_t xstep = (int64_t)CK * HW * 4;
+  const char* wb = reinterpret_cast<const char*>(w) + (DGRAD ? (int64_t)co0 * 9 * 4 : (int64_t)co0 * s.Cin * 9 * 4);
+  int64_t wbytes = (int64_t)s.Cin * s.Cout * 9 * 4 - (wb - reinterpret_cast<const char*>(w));
+  const int64_t wstep = DGRAD ? (int64_t)CK * s.Cout * 9 * 4 : (int64_t)CK * 9 * 4;
+
+  auto issue = [&](int c0, float* buf) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wb), 0, (int)wbytes, 0x00020000);
+    const int cvalid = s.Cin - c0;                              // channels of this chunk that exist (>= CK: all)
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+      uint32_t off = poff[i];
+      if (cvalid < CK) off = ((i * CT_THREADS + (int)threadIdx.x) / P::CPC < cvalid) ? off : DMA_OOB;
+      if ((i + 1) * CT_THREADS <= PCH || i * CT_THREADS + (int)threadIdx.x < PCH)
+        dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
+    }
+#pragma unroll
+    for (int i = 0; i < NVW; ++i) {
+      uint32_t off = woff[i];
+      if (cvalid < CK) {
+        const int e = i * CT_THREADS + (int)threadIdx.x;
+        const bool in = DGRAD ? (e / F::QW < cvalid) : (4 * (e % F::QW) < cvalid * 9);
+        off = in ? off : DMA_OOB;
+      }
+      if ((i + 1) * CT_THREADS <= WCH || i * CT_THREADS + (int)threadIdx.x < WCH)
+        dma16(rw, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
+    }
+    xb += xstep; xbytes -= xstep;
+    wb += wstep; wbytes -= wstep;
+  };
+
+  // ---- fragment addresses
+  int lane_b[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) lane_b[n] = (h + g0 * KG) * P::CIS + P::pix(pix0 + n * MF + j);
+  // forward: A[m = co][k = (ci, tap)] = wl[co * RS + ci * 9 + tap];  dgrad: A[m][k = (kc, tap)] = wl[kc * RS + m * 9 + 8 - tap]
+  const int lane_a = DGRAD ? ((h + g0 * KG) * F::RS + j * 9 + 8) : (j * F::RS + (h + g0 * KG) * 9);
+
+  typename Core::acc_t acc[MT][NT];
+  Core::zero(acc);
+
+  issue(0, lds);
+  int buf = 0;
+  for (int c0 = 0; c0 < s.Cin; c0 += CK) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMAs of chunk c0 have landed ...
+    __syncthreads();                                           // ... and everybody's; everybody is done reading the other buffer
+    if (c0 + CK < s.Cin) issue(c0 + CK, lds + (buf ^ 1) * BUF);
+    const float* pl = lds + buf * BUF;
+    const float* wl = pl + PBUF;
+#pragma unroll
+    for (int gi = 0; gi < NG / (WK ? 4 : 1); ++gi) {
+      const int g = gi * (WK ? 4 : 1);                           // (+ g0, in the lane bases)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        float a[MT], b[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          a[m] = DGRAD ? wl[lane_a + (g * KG) * F::RS + m * MF * 9 - tap] : wl[lane_a + m * MF * F::RS + (g * KG) * 9 + tap];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[n] = pl[lane_b[n] + (g * KG) * P::CIS + kh * P::PWS + kw];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if constexpr (MF == 32)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            else
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+          }
+      }
+    }
+    buf ^= 1;
+  }
+  if constexpr (WK) {
+    // sum the four waves' partial accumulators through LDS (fixed order), as conv_fwd_kernel does
     __syncthreads();
     float* red = lds;
 #pragma unroll
@@ -1421,8 +1620,85 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, const floa
   return tg_launch_status();
 }
 
+// ---- LDS-DMA kernel dispatch.  Tuning knobs are read once from the environment (development only; the defaults are the
+// measured best): TG_CONV_DMA=0 disables the kernel, TG_DMA_TILE=256|512 and TG_DMA_CK=4|8 force a tile / chunk size.
+struct DmaKnobs { int enable, tile, ck, ksplit; };
+static const DmaKnobs& dma_knobs() {
+  static const DmaKnobs k = [] {
+    DmaKnobs d{1, 0, 0, 1};
+    if (const char* e = getenv("TG_DMA_KSPLIT")) d.ksplit = atoi(e);
+    if (const char* e = getenv("TG_CONV_DMA")) d.enable = atoi(e);
+    if (const char* e = getenv("TG_DMA_TILE")) d.tile = atoi(e);
+    if (const char* e = getenv("TG_DMA_CK")) d.ck = atoi(e);
+    return d;
+  }();
+  return k;
+}
+
+template <class G, int CK, bool DGRAD>
+static bool launch_dma_geo(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
+  const int64_t tiles = num_tiles<G>(s.B, s.H, s.W);
+  const int swz = (tiles % 8 == 0) ? 1 : 0;
+  const bool use32 = (s.Cout % 32 == 0) || s.Cout > 48;
+  // output-channel tile: as wide as the grid allows (one workgroup per CU at the very least)
+  if (use32 && s.Cout > 32 && tiles * ((s.Cout + 63) / 64) >= 512) {
+    conv_dma_kernel<G, 32, 2, CK, DGRAD><<<dim3(tiles, (s.Cout + 63) / 64), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
+  } else if (use32 && tiles * ((s.Cout + 31) / 32) >= 256) {
+    conv_dma_kernel<G, 32, 1, CK, DGRAD><<<dim3(tiles, (s.Cout + 31) / 32), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
+  } else if (tiles * ((s.Cout + 15) / 16) >= 192) {
+    conv_dma_kernel<G, 16, 1, CK, DGRAD><<<dim3(tiles, (s.Cout + 15) / 16), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
+  } else {
+    return false;                      // too few tiles: the K-split variants of conv_fwd_kernel fill the chip better
+  }
+  return true;
+}
+
+template <class G, bool DGRAD>
+static bool launch_dma_ksplit(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
+  const int64_t tiles = num_tiles<G>(s.B, s.H, s.W);
+  const int swz = (tiles % 8 == 0) ? 1 : 0;
+  if (s.Cout % 32 == 0 || s.Cout > 48)
+    conv_dma_kernel<G, 32, 1, 16, DGRAD><<<dim3(tiles, (s.Cout + 31) / 32), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
+  else
+    conv_dma_kernel<G, 16, 1, 16, DGRAD><<<dim3(tiles, (s.Cout + 15) / 16), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
+  return true;
+}
+
+// -> true when the LDS-DMA kernel took the launch
+template <bool DGRAD>
+static bool try_launch_dma(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st,
+                           int* rc) {
+  const DmaKnobs& k = dma_knobs();
+  if (!k.enable) return false;
+  if (s.W % 4 != 0 || !tg_aligned16(x) || !tg_aligned16(w) || s.Cin % 4 != 0 || s.Cout % 4 != 0) return false;
+  if ((int64_t)s.B * s.Cin * s.H * s.W * 4 >= (1ll << 31) || (int64_t)s.Cin * s.Cout * 36 >= (1ll << 31)) return false;
+  // channel chunk: 4 keeps more workgroups resident (17 KB of LDS) and wins on the short-K layers; 8 halves the barriers
+  const bool ck4 = (k.ck == 4) || (k.ck == 0 && s.Cin <= 16);
+  bool took = false;
+  if (s.H % 16 == 0 && s.W % 32 == 0 && k.tile == 512) {
+    took = ck4 ? launch_dma_geo<GX2, 4, DGRAD>(x, w, bias, residual, y, s, st) : launch_dma_geo<GX2, 8, DGRAD>(x, w, bias, residual, y, s, st);
+  } else if (s.H % 8 == 0 && s.W % 32 == 0) {
+    took = ck4 ? launch_dma_geo<GX, 4, DGRAD>(x, w, bias, residual, y, s, st) : launch_dma_geo<GX, 8, DGRAD>(x, w, bias, residual, y, s, st);
+  } else if (s.H == 16 && s.W == 16) {
+    took = ck4 ? launch_dma_geo<G16, 4, DGRAD>(x, w, bias, residual, y, s, st) : launch_dma_geo<G16, 8, DGRAD>(x, w, bias, residual, y, s, st);
+  }
+  if (!took && s.Cin >= 16 && k.ksplit) {
+    // small planes with long K: 64-pixel tiles, the four waves split each 16-channel chunk (one workgroup per CU is the
+    // normal case here, so the chunk DMA under the MFMAs is the only overlap there is)
+    if (s.H == 8 && s.W == 8) took = launch_dma_ksplit<G8k, DGRAD>(x, w, bias, residual, y, s, st);
+    else if (s.H == 4 && s.W == 4) took = launch_dma_ksplit<G4k, DGRAD>(x, w, bias, residual, y, s, st);
+    else if (s.H == 16 && s.W == 16) took = launch_dma_ksplit<G16k, DGRAD>(x, w, bias, residual, y, s, st);
+  }
+  if (took) *rc = tg_launch_status();
+  return took;
+}
+
 template <int KS, bool DGRAD>
 int launch_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
+  if constexpr (KS == 3) {
+    int rc = 0;
+    if (try_launch_dma<DGRAD>(x, w, bias, residual, y, s, st, &rc)) return rc;
+  }
   // small layers: if 256-pixel tiles cannot even give every other CU a workgroup, use 64-pixel tiles whose waves
   // split K (4x the workgroups, each wave 1/4 of the k-groups).  Measured at batch 64: 128->128 @ 16^2 (128
   // such workgroups) runs 65 us unsplit vs 74 us split; @ 8^2 (32) 55 us vs 24 us.

@@ -30,15 +30,35 @@ def _ws(like, nbytes):
     return torch.empty(max(1, (int(nbytes) + 3) // 4), dtype=torch.float32, device=like.device)
 
 
+class _GradSinks:
+    active = False
+
+
+@contextlib.contextmanager
+def grads_into_buckets():
+    """Opt-in for the direct parameter-gradient path (see ``_grad_sink``), entered by the trainers around their own
+    ``backward`` calls only.  Outside it every Function returns its parameter gradients to autograd like any other op,
+    so ``torch.autograd.grad(loss, params)``, ``backward(inputs=subset)``, tensor hooks and AccumulateGrad post-hooks
+    (DDP, gradient clipping hooks) of a foreign training loop behave as with stock modules."""
+    prev = _GradSinks.active
+    _GradSinks.active = True
+    try:
+        yield
+    finally:
+        _GradSinks.active = prev
+
+
 def _grad_sink(p):
     """Where a parameter gradient can be accumulated in place, or None.
 
-    In a plain ``.backward()`` (no create_graph) the gradient of a leaf parameter that already owns
-    a ``.grad`` buffer (tartangan_amd.optim keeps them as views of one flat bucket per network) is
-    written by the producing kernel straight into that buffer with accumulate semantics, and the
-    Function returns ``None`` for it.  That is exactly what autograd's AccumulateGrad would do with a
-    returned tensor, minus one temporary and one elementwise-add launch per parameter.
+    Inside ``grads_into_buckets()``, in a plain ``.backward()`` (no create_graph), the gradient of a leaf
+    parameter that already owns a ``.grad`` buffer (tartangan_amd.optim keeps them as views of one flat
+    bucket per network) is written by the producing kernel straight into that buffer with accumulate
+    semantics, and the Function returns ``None`` for it.  That is exactly what autograd's AccumulateGrad
+    would do with a returned tensor, minus one temporary and one elementwise-add launch per parameter.
     """
+    if not _GradSinks.active:
+        return None
     if p is None or torch.is_grad_enabled() or not (p.is_leaf and p.requires_grad):
         return None
     g = p.grad
@@ -158,7 +178,8 @@ def deferred_wgrad():
     outer = _DeferredWgrad.active
     _DeferredWgrad.active = True
     try:
-        yield
+        with grads_into_buckets():      # the batched reduce only exists for gradients that go straight into .grad
+            yield
     finally:
         _DeferredWgrad.active = outer
         if not outer:

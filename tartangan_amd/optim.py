@@ -22,8 +22,13 @@ def flatten_parameters(module):
     ``load_state_dict`` / in-place updates keep working because they copy into the views.
     """
     params = [p for p in module.parameters()]
-    if getattr(module, '_tg_flat', None) is not None:
-        return module._tg_flat
+    cached = getattr(module, '_tg_flat', None)
+    if cached is not None and _is_bound(params, *cached):
+        return cached
+    # first call, or the binding was broken from outside: module.to(), zero_grad(set_to_none=True), p.grad = None,
+    # torch.save(module) / torch.load (the reference's ModelCheckpoint pickles whole models,
+    # components/model_checkpoint.py:35-45) all leave parameters that are no longer views of the buckets.
+    # Rebuild from the CURRENT parameter (and gradient) values.
     n = sum(p.numel() for p in params)
     dev = params[0].device
     flat = torch.empty(n, dtype=torch.float32, device=dev)
@@ -33,11 +38,26 @@ def flatten_parameters(module):
         for p in params:
             k = p.numel()
             flat[off:off + k].copy_(p.detach().reshape(-1))
+            if p.grad is not None:
+                grads[off:off + k].copy_(p.grad.detach().reshape(-1))
             p.data = flat[off:off + k].view(p.shape)
             p.grad = grads[off:off + k].view(p.shape)
             off += k
     module._tg_flat = (flat, grads)
     return flat, grads
+
+
+def _is_bound(params, flat, grads):
+    """Host-side check (pointer compares only) that every parameter / gradient is still the view it was made."""
+    off, fp, gp = 0, flat.data_ptr(), grads.data_ptr()
+    for p in params:
+        if p.device != flat.device or p.data_ptr() != fp + 4 * off:
+            return False
+        g = p.grad
+        if g is None or g.data_ptr() != gp + 4 * off or not g.is_contiguous():
+            return False
+        off += p.numel()
+    return off == flat.numel()
 
 
 class FusedAdam:
@@ -56,16 +76,47 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
+        self.generation = 0          # bumped whenever the buckets had to be rebuilt (captured graphs are then stale)
+        self._make_hyper()
+
+    def _make_hyper(self):
         self._hyper = torch.zeros(6, dtype=torch.float32, device=self.flat.device)
         self._hyper_host = torch.zeros(6, dtype=torch.float32)
         if self.flat.is_cuda:
             self._hyper_host = self._hyper_host.pin_memory()
 
+    def ensure_bound(self):
+        """Re-home the parameters if something outside detached them from the buckets (see flatten_parameters); without
+        this, autograd would allocate fresh ``.grad`` tensors and Adam would step on a stale zero bucket."""
+        flat, grads = flatten_parameters(self.module)
+        if flat is not self.flat or grads is not self.grads:
+            if flat.numel() != self.exp_avg.numel():
+                raise RuntimeError('FusedAdam: the module gained or lost parameters after the optimiser was built')
+            self.flat, self.grads = flat, grads
+            if self.exp_avg.device != flat.device:
+                self.exp_avg, self.exp_avg_sq = self.exp_avg.to(flat.device), self.exp_avg_sq.to(flat.device)
+                self._make_hyper()
+            self.generation += 1
+        return self.generation
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_hyper_host', None)       # pinned host memory does not pickle as pinned; rebuilt on load
+        state.pop('_hyper', None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.flat, self.grads = flatten_parameters(self.module)     # unpickled parameters are plain tensors again
+        self._make_hyper()
+
     def zero_grad(self, set_to_none=False):
+        self.ensure_bound()
         _be.get().fill(self.grads, 0.0, self.grads.numel())
 
     def advance(self):
         """Host half of a step: bump the step index and upload its scalars (not capturable)."""
+        self.ensure_bound()
         self.step_count += 1
         b1, b2 = self.betas
         bc1 = 1 - b1 ** self.step_count
@@ -89,6 +140,9 @@ class FusedAdam:
 
     def load_state_dict(self, sd):
         self.step_count = int(sd['step'])
+        self.lr = float(sd.get('lr', self.lr))
+        self.betas = tuple(float(b) for b in sd.get('betas', self.betas))
+        self.eps = float(sd.get('eps', self.eps))
         self.exp_avg.copy_(sd['exp_avg'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])
 

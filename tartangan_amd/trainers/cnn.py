@@ -13,6 +13,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from .. import backend as _be
 from .. import functional as TF
 from ..models.blocks import (
     DiscriminatorOutput, GeneratorInputMLP, GeneratorOutput, ResidualDiscriminatorBlock,
@@ -196,11 +197,27 @@ class CNNTrainer(Trainer):
         feed = self.rng_feed
         if self._graphs is None and not feed.plan:
             return self._train_batch_eager(imgs)               # call 1: eager, records the RNG plan
+        gen = (self.optimizer_d.ensure_bound(), self.optimizer_g.ensure_bound())
+        if self._graphs is not None and (gen != self._graph_gen or imgs.shape != self._static_imgs.shape):
+            if imgs.shape != self._static_imgs.shape:
+                # a ragged last batch: the captured graphs are for one batch shape; run this call eagerly
+                # (the RNG plan is per shape too, so draw directly)
+                mode, feed.mode = feed.mode, 'off'
+                try:
+                    return self._train_batch_eager(imgs)
+                finally:
+                    feed.mode = mode
+            self._graphs = None                                # parameter buckets were rebuilt: recapture
         feed.refill()
         if self._graphs is None:                               # call 2: capture (nothing executes yet)
             try:
                 self._capture(imgs)
-            except Exception as exc:                           # e.g. a collective library that refuses capture
+                self._graph_gen = gen
+            except _be.KernelError:
+                raise                                          # a tg_* call failed: a real error, never downgraded
+            except RuntimeError as exc:                        # e.g. a collective library that refuses capture
+                if 'capture' not in str(exc).lower() and 'graph' not in str(exc).lower():
+                    raise
                 import warnings
                 warnings.warn(f'HIP-graph capture failed ({exc!r}); continuing in eager mode')
                 self._graph_requested = False

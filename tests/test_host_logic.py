@@ -5,6 +5,8 @@ the golden fixtures produced by the reference and with the oracle.
 
 These tests say nothing about the HIP kernels (that is tests/test_*_gpu.py); they
 pin everything between the C ABI and the reference's Python API."""
+import contextlib
+
 import pytest
 import torch
 
@@ -262,11 +264,44 @@ def test_tall_linear_weight_gradient_is_row_sliced_and_equals_torch():
     x = torch.randn(512, 48)
     lin = torch.nn.Linear(48, 24)
     w, b = torch.nn.Parameter(lin.weight.detach().clone()), torch.nn.Parameter(lin.bias.detach().clone())
-    for _ in range(2):                              # second pass: .grad exists -> accumulate-in-place path
-        TF.linear(x, w, b).tanh().sum().backward()
+    for k in range(2):                              # second pass: .grad exists -> accumulate-in-place path (opt-in)
+        with (TF.grads_into_buckets() if k else contextlib.nullcontext()):
+            TF.linear(x, w, b).tanh().sum().backward()
         torch.nn.functional.linear(x, lin.weight, lin.bias).tanh().sum().backward()
         assert torch.allclose(w.grad, lin.weight.grad, rtol=1e-4, atol=1e-4)
         assert torch.allclose(b.grad, lin.bias.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_foreign_training_loop_sees_stock_autograd_semantics():
+    """INTEGRATION.md section 2 invites foreign training loops on these modules: outside the trainers' own
+    ``grads_into_buckets()`` scope a backward must behave like stock modules -- ``torch.autograd.grad`` returns every
+    parameter gradient and leaves ``.grad`` alone, ``backward(inputs=subset)`` touches only the subset, tensor hooks
+    fire -- even though every parameter already owns a ``.grad`` view into the optimiser's flat bucket."""
+    fx = load_golden('c32a2_cnn_b8')
+    tr = make_trainer(fx)
+    tr.d.load_state_dict(procedural_state(tr.d.state_dict(), 5))
+    imgs = synthetic_images(4, 32, 3)
+    params = list(tr.d.parameters())
+    assert all(p.grad is not None for p in params)           # FusedAdam bound the flat bucket
+    tr.optimizer_d.zero_grad()
+    loss = TF.bce_with_logits(tr.d(imgs), torch.ones(4, 1))
+    got = torch.autograd.grad(loss, params, retain_graph=True)
+    assert all(g is not None for g in got)
+    assert float(tr.optimizer_d.grads.abs().max()) == 0.0    # .grad untouched
+    fired = []
+    handle = params[0].register_hook(lambda g: fired.append(g.clone()))
+    loss.backward(inputs=params[:3], retain_graph=True)
+    handle.remove()
+    assert len(fired) == 1 and torch.allclose(fired[0], got[0], rtol=1e-5, atol=1e-7)
+    for p, g in zip(params[:3], got[:3]):
+        assert torch.allclose(p.grad, g, rtol=1e-5, atol=1e-7)
+    for p in params[3:]:
+        assert float(p.grad.abs().max()) == 0.0              # not in `inputs`: not written
+    tr.optimizer_d.zero_grad()
+    with TF.deferred_wgrad():                                 # the trainers' path: straight into the bucket
+        loss.backward()
+    for p, g in zip(params, got):
+        assert torch.allclose(p.grad, g, rtol=1e-4, atol=1e-6), (p.shape,)
 
 
 def test_product_has_no_cpu_fallback():
