@@ -167,6 +167,38 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma /*nullable*/, const float
                    float* adj_gz, float* adj_x, float* adj_gamma, float* workspace,
                    int B, int C, int HW, void* stream);
 
+/* ---- BatchNorm under data parallelism (SyncBN; SURVEY.md 8e collective 3).  The reference normalises over the whole
+ * batch (trainers/cnn.py:122-123 evaluates D on all B images); when the batch is sharded over ranks the same numbers
+ * need global statistics.  Each pass is split in three: *_local writes this rank's per-channel sums (float64,
+ * [C][K] channel-major: K = 3 statistics (mean, mean^2, biased var), K = 2 first backward, K = 5 second backward), the
+ * CALLER all-reduces them (SUM; torch.distributed -- RCCL on device buffers), *_finish completes the pass with the
+ * global sums.  count_global = world * B * HW (equal shards).  Parameter gradients (ggamma, gbeta, adj_gamma) come out as
+ * this rank's share, to be averaged by the gradient all-reduce like every other parameter gradient.
+ * Workspace: tg_bn_workspace(B, C, HW) bytes; the *_finish call of the backward passes must get the same workspace
+ * pointer contents-wise only in that it is scratch (nothing is carried from *_local).                              */
+int tg_bn_sync_stats_local(const float* x, double* sums /*[C][3]*/, float* workspace, int B, int C, int HW,
+                           void* stream);
+int tg_bn_sync_stats_finish(const double* sums /*[C][3], all-reduced*/, int world, float* mean, float* invstd,
+                            float* running_mean /*nullable*/, float* running_var /*nullable*/,
+                            int64_t* num_batches_tracked /*nullable*/, float momentum, float eps,
+                            int64_t count_global, int replicate, int C, void* stream);
+int tg_bn_sync_bwd_local(const float* gz, const float* x, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, float slope, double* sums /*[C][2]*/,
+                         float* workspace, int B, int C, int HW, void* stream);
+int tg_bn_sync_bwd_finish(const float* gz, const float* x, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, float slope,
+                          const double* local_sums /*[C][2]*/, const double* global_sums /*[C][2], all-reduced*/,
+                          int64_t count_global, float* gx /*nullable*/, float* ggamma, float* gbeta,
+                          float* workspace, int B, int C, int HW, int accumulate, void* stream);
+int tg_bn_sync_dbwd_local(const float* v, const float* gz, const float* x, const float* mean,
+                          const float* invstd, const float* gamma, const float* beta, float slope,
+                          double* sums /*[C][5]*/, float* workspace, int B, int C, int HW, void* stream);
+int tg_bn_sync_dbwd_finish(const float* v, const float* gz, const float* x, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, float slope,
+                           const double* global_sums /*[C][5], all-reduced*/, int64_t count_global, int world,
+                           float* adj_gz, float* adj_x, float* adj_gamma, float* workspace,
+                           int B, int C, int HW, void* stream);
+
 /* ---------------------------------------------------------------- resampling
  * F.interpolate(scale_factor=2,'nearest') generator.py:58 and nn.AvgPool2d(2)
  * discriminator.py:67 are transposes of each other up to a factor:

@@ -22,6 +22,7 @@ LIBRARY = os.path.join(_HERE, 'csrc', 'libtartangan_amd.so')
 _CTYPES = {
     'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p,
     'const uint8_t*': ctypes.c_void_p, 'uint8_t*': ctypes.c_void_p, 'int64_t*': ctypes.c_void_p,
+    'const double*': ctypes.c_void_p, 'double*': ctypes.c_void_p,
     'void*': ctypes.c_void_p, 'int': ctypes.c_int, 'int64_t': ctypes.c_int64,
     'size_t': ctypes.c_size_t, 'float': ctypes.c_float, 'const char*': ctypes.c_char_p,
     'const tg_host_i64*': ctypes.c_void_p,          # HOST array (a CPU int64 tensor), not a device pointer
@@ -46,6 +47,10 @@ def parse_header(path=HEADER):
                 params.append((typ, mm.group(2)))
         protos[name] = (ret, params)
     return protos
+
+
+class KernelError(RuntimeError):
+    """A tg_* entry point returned a non-zero code (bad argument, unsupported shape or a HIP error)."""
 
 
 class HipBackend:
@@ -99,7 +104,7 @@ class HipBackend:
                 args.append(torch.cuda.current_stream().cuda_stream)
             rc = fn(*args)
             if checked and rc != 0:
-                raise RuntimeError(f'{name} failed with code {rc}')
+                raise KernelError(f'{name} failed with code {rc}')
             return rc
         call.__name__ = name
         return call

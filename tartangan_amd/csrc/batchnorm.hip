@@ -511,6 +511,87 @@ __global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------ data-parallel BatchNorm (SyncBN)
+// Three steps per pass: local per-channel sums (fp64, [C][K] channel-major) -> all-reduce SUM by the caller
+// (torch.distributed: RCCL / gloo) -> finish with the global sums.  Equal shard sizes on every rank.
+//   statistics K = 3: (mean_r, mean_r^2, var_r) -- the union's mean is the mean of the local means, its biased variance
+//                     the mean of the local variances plus the variance of the local means (fp64: no cancellation issue)
+//   backward   K = 2: (sum ghat, sum ghat*xhat) with the GLOBAL mean / invstd
+//   second bwd K = 5: S1..S5 of tg_bn_act_dbwd
+__global__ void sync_stats_pack(const double* __restrict__ partial, const float* __restrict__ x, double* __restrict__ sums,
+                                int B, int C, int HW, int S) {
+  const int c = blockIdx.x;                       // one wave per channel
+  const double n = (double)B * HW;
+  const double pivot = (double)x[(int64_t)c * HW];
+  const double s1 = planes::gather(partial, c, S, 2, 0) / n;
+  const double s2 = planes::gather(partial, c, S, 2, 1) / n;
+  if (threadIdx.x != 0) return;
+  const double m = pivot + s1;
+  double var = s2 - s1 * s1;
+  if (var < 0.0) var = 0.0;
+  sums[c * 3 + 0] = m; sums[c * 3 + 1] = m * m; sums[c * 3 + 2] = var;
+}
+
+__global__ void sync_stats_finish(const double* __restrict__ sums, int world, float* __restrict__ mean, float* __restrict__ invstd,
+                                  float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt, float momentum,
+                                  float eps, double count, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt != nullptr) *nbt += 1;
+  if (c >= C) return;
+  const double w = (double)world;
+  const double m = sums[c * 3 + 0] / w;
+  double var = sums[c * 3 + 2] / w + (sums[c * 3 + 1] / w - m * m);
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rm != nullptr) {
+    const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * m);
+    rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
+  }
+}
+
+template <int K>
+__global__ void sync_sums_pack(const double* __restrict__ partial, double* __restrict__ sums, int S) {
+  const int c = blockIdx.x;                       // one wave per channel
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const double v = planes::gather(partial, c, S, K, k);
+    if (threadIdx.x == 0) sums[c * K + k] = v;
+  }
+}
+
+// parameter gradients from the LOCAL sums (the gradient all-reduce averages them like every other parameter gradient),
+// the input-gradient coefficients from the GLOBAL sums over the global element count
+__global__ void sync_bwd_finish(const double* __restrict__ local, const double* __restrict__ global, double count,
+                                float* __restrict__ ggamma, float* __restrict__ gbeta, float* __restrict__ coef, int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  gbeta[c] = (float)local[c * 2 + 0] + (accumulate ? gbeta[c] : 0.f);
+  ggamma[c] = (float)local[c * 2 + 1] + (accumulate ? ggamma[c] : 0.f);
+  coef[c * COEF + 0] = (float)(global[c * 2 + 0] / count);
+  coef[c * COEF + 1] = (float)(global[c * 2 + 1] / count);
+}
+
+// dbwd_stage2 on the global sums; adj_gamma is this rank's 1/world share of r*A (the shares add up to the global adjoint
+// under the gradient all-reduce; see DESIGN.md "SyncBN")
+__global__ void sync_dbwd_finish(const double* __restrict__ global, double count, int world, const float* __restrict__ gamma,
+                                 const float* __restrict__ invstd, float* __restrict__ adj_gamma, float* __restrict__ coef, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = count;
+  const double S1 = global[c * 5 + 0], S2 = global[c * 5 + 1], S3 = global[c * 5 + 2], S4 = global[c * 5 + 3], S5 = global[c * 5 + 4];
+  const double r = (double)invstd[c], g = (double)gamma[c];
+  const double A = S5 - S1 * S3 / n - S2 * S4 / n;
+  const double cg = S4 / n, cv = S2 / n;
+  const double qm = -g * r * (cg * S1 / n + cv * S3 / n);
+  const double qx = -g * r * (cg * S2 / n + cv * S4 / n);
+  adj_gamma[c] = (float)(r * A / (double)world);
+  float* k = coef + c * COEF;
+  k[0] = (float)(S1 / n); k[1] = (float)(S2 / n); k[2] = (float)cg; k[3] = (float)cv;
+  k[4] = (float)qm; k[5] = (float)qx; k[6] = (float)(g * A * r * r / n);
+}
+
 }  // namespace
 
 extern "C" {
@@ -630,6 +711,92 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, cons
   dbwd_stage2<<<C, 64, 0, st>>>(p.partial, gamma, invstd, vgamma, adj_gamma, p.coef, B, C, HW,
                                            planes::splits(B, C, HW));
   DbwdBody body{v, gz, x, adj_gz, adj_x, mean, invstd, gamma, beta, vgamma, vbeta, p.coef, slope};
+  planes::launch_map(body, B, C, HW, st, al);
+  return tg_launch_status();
+}
+
+int tg_bn_sync_stats_local(const float* x, double* sums, float* workspace, int B, int C, int HW, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(sums); TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  hipStream_t st = tg_stream(stream);
+  Parts p = split_ws(workspace, B, C, HW);
+  RedStats red{x, C, HW, 0.f};
+  planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x));
+  sync_stats_pack<<<C, 64, 0, st>>>(p.partial, x, sums, B, C, HW, planes::splits(B, C, HW));
+  return tg_launch_status();
+}
+
+int tg_bn_sync_stats_finish(const double* sums, int world, float* mean, float* invstd, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, float momentum, float eps, int64_t count_global, int replicate, int C,
+                            void* stream) {
+  TG_CHECK_PTR(sums); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd);
+  TG_CHECK_POS(world); TG_CHECK_POS(C); TG_CHECK_POS(replicate);
+  if (count_global <= 0 || (running_mean == nullptr) != (running_var == nullptr)) return TG_EINVAL;
+  sync_stats_finish<<<chan_grid(C), 64, 0, tg_stream(stream)>>>(sums, world, mean, invstd, running_mean, running_var,
+                                                                   num_batches_tracked, momentum, eps,
+                                                                   (double)count_global * replicate, C);
+  return tg_launch_status();
+}
+
+int tg_bn_sync_bwd_local(const float* gz, const float* x, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, float slope, double* sums, float* workspace, int B, int C, int HW, void* stream) {
+  TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta);
+  TG_CHECK_PTR(sums); TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  hipStream_t st = tg_stream(stream);
+  Parts p = split_ws(workspace, B, C, HW);
+  RedBwd red{gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
+  planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz));
+  sync_sums_pack<2><<<C, 64, 0, st>>>(p.partial, sums, planes::splits(B, C, HW));
+  return tg_launch_status();
+}
+
+int tg_bn_sync_bwd_finish(const float* gz, const float* x, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, float slope, const double* local_sums, const double* global_sums,
+                          int64_t count_global, float* gx, float* ggamma, float* gbeta, float* workspace, int B, int C, int HW,
+                          int accumulate, void* stream) {
+  TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta);
+  TG_CHECK_PTR(local_sums); TG_CHECK_PTR(global_sums); TG_CHECK_PTR(ggamma); TG_CHECK_PTR(gbeta); TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  if (count_global <= 0) return TG_EINVAL;
+  hipStream_t st = tg_stream(stream);
+  Parts p = split_ws(workspace, B, C, HW);
+  sync_bwd_finish<<<chan_grid(C), 64, 0, st>>>(local_sums, global_sums, (double)count_global, ggamma, gbeta, p.coef, C, accumulate);
+  if (gx != nullptr) {
+    BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, 1};
+    planes::launch_map(body, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx));
+  }
+  return tg_launch_status();
+}
+
+int tg_bn_sync_dbwd_local(const float* v, const float* gz, const float* x, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, float slope, double* sums, float* workspace, int B, int C,
+                          int HW, void* stream) {
+  TG_CHECK_PTR(v); TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma);
+  TG_CHECK_PTR(beta); TG_CHECK_PTR(sums); TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  hipStream_t st = tg_stream(stream);
+  Parts p = split_ws(workspace, B, C, HW);
+  RedDbwd red{v, gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
+  planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(v));
+  sync_sums_pack<5><<<C, 64, 0, st>>>(p.partial, sums, planes::splits(B, C, HW));
+  return tg_launch_status();
+}
+
+int tg_bn_sync_dbwd_finish(const float* v, const float* gz, const float* x, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, float slope, const double* global_sums, int64_t count_global,
+                           int world, float* adj_gz, float* adj_x, float* adj_gamma, float* workspace, int B, int C, int HW,
+                           void* stream) {
+  TG_CHECK_PTR(v); TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma);
+  TG_CHECK_PTR(beta); TG_CHECK_PTR(global_sums); TG_CHECK_PTR(adj_gz); TG_CHECK_PTR(adj_x); TG_CHECK_PTR(adj_gamma);
+  TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW); TG_CHECK_POS(world);
+  if (count_global <= 0) return TG_EINVAL;
+  hipStream_t st = tg_stream(stream);
+  Parts p = split_ws(workspace, B, C, HW);
+  sync_dbwd_finish<<<chan_grid(C), 64, 0, st>>>(global_sums, (double)count_global, world, gamma, invstd, adj_gamma, p.coef, C);
+  DbwdBody body{v, gz, x, adj_gz, adj_x, mean, invstd, gamma, beta, nullptr, nullptr, p.coef, slope};
+  const bool al = tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(v) && tg_aligned16(adj_gz) && tg_aligned16(adj_x);
   planes::launch_map(body, B, C, HW, st, al);
   return tg_launch_status();
 }

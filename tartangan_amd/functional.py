@@ -612,57 +612,93 @@ def linear(x, weight, bias=None):
 
 
 # =========================================================================== BatchNorm (+LeakyReLU)
+class SyncGroup:
+    """Handle a BatchNorm2d carries in a data-parallel run with synchronised statistics (parallel.DataParallel(sync_bn=True)):
+    every pass all-reduces its per-channel sums over ``group`` (tg_bn_sync_*: local sums -> all-reduce -> finish)."""
+
+    def __init__(self, group, world):
+        self.group, self.world = group, int(world)
+
+    def all_reduce(self, sums):
+        import torch.distributed as dist
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        return sums
+
+
+def _sums(like, C, k):
+    return torch.empty(C * k, dtype=torch.float64, device=like.device)
+
+
 class _BNAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, num_batches_tracked=None,
-                replicate=1):
+                replicate=1, sync=None):
         x = x.contiguous()
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         mean, invstd = x.new_empty(C), x.new_empty(C)
         z = torch.empty_like(x)
-        if training:
+        if training and sync is not None and sync.world > 1:
+            ws = _ws(x, K().bn_workspace(B, C, hw))
+            sums = _sums(x, C, 3)
+            K().bn_sync_stats_local(x, sums, ws, B, C, hw)
+            sync.all_reduce(sums)
+            K().bn_sync_stats_finish(sums, sync.world, mean, invstd, running_mean, running_var, num_batches_tracked,
+                                     float(momentum), float(eps), sync.world * B * hw, int(replicate), C)
+            K().bn_act_fwd(x, mean, invstd, gamma, beta, float(slope), z, B, C, hw)
+        elif training:
+            sync = None
             ws = _ws(x, K().bn_workspace(B, C, hw))
             K().bn_train_fwd(x, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta,
                              float(slope), float(momentum), float(eps), z, ws, B, C, hw, int(replicate))
         else:
+            sync = None
             K().bn_eval_stats(running_mean, running_var, mean, invstd, float(eps), C)
             K().bn_act_fwd(x, mean, invstd, gamma, beta, float(slope), z, B, C, hw)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
-        ctx.training, ctx.slope = bool(training), float(slope)
+        ctx.training, ctx.slope, ctx.sync = bool(training), float(slope), sync
         return z
 
     @staticmethod
     def backward(ctx, gz):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
         sink_g, sink_b = _grad_sink(gamma), _grad_sink(beta)
+        nones = (None,) * 9
         if sink_g is not None and sink_b is not None:
             # plain backward: ggamma / gbeta accumulate straight into the flat bucket
             gz = gz.contiguous()
-            B, C = x.shape[0], x.shape[1]
-            hw = x[0, 0].numel()
             gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-            ws = _ws(x, K().bn_workspace(B, C, hw))
-            K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, ctx.slope, int(ctx.training), gx, sink_g, sink_b, ws,
-                           B, C, hw, 1)
-            return gx, None, None, None, None, None, None, None, None, None, None
+            _bn_bwd_into(gz, x, mean, invstd, gamma, beta, ctx.slope, ctx.training, gx, sink_g, sink_b, 1, ctx.sync)
+            return (gx, None, None) + nones
         gx, gg, gb = _BNActBwd.apply(gz, x, gamma, beta, mean, invstd, ctx.slope, ctx.training,
-                                     ctx.needs_input_grad[0])
-        return gx, gg, gb, None, None, None, None, None, None, None, None
+                                     ctx.needs_input_grad[0], ctx.sync)
+        return (gx, gg, gb) + nones
+
+
+def _bn_bwd_into(gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, accumulate, sync):
+    B, C = x.shape[0], x.shape[1]
+    hw = x[0, 0].numel()
+    ws = _ws(x, K().bn_workspace(B, C, hw))
+    if sync is None:
+        K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, slope, int(training), gx, gg, gb, ws, B, C, hw, accumulate)
+        return
+    local = _sums(x, C, 2)
+    K().bn_sync_bwd_local(gz, x, mean, invstd, gamma, beta, slope, local, ws, B, C, hw)
+    glob = sync.all_reduce(local.clone())
+    K().bn_sync_bwd_finish(gz, x, mean, invstd, gamma, beta, slope, local, glob, sync.world * B * hw, gx, gg, gb, ws,
+                           B, C, hw, accumulate)
 
 
 class _BNActBwd(Function):
     @staticmethod
-    def forward(ctx, gz, x, gamma, beta, mean, invstd, slope, training, need_gx=True):
+    def forward(ctx, gz, x, gamma, beta, mean, invstd, slope, training, need_gx=True, sync=None):
         gz = gz.contiguous()
-        B, C = x.shape[0], x.shape[1]
-        hw = x[0, 0].numel()
+        C = x.shape[1]
         gx = torch.empty_like(x) if need_gx else None
         gg, gb = x.new_empty(C), x.new_empty(C)
-        ws = _ws(x, K().bn_workspace(B, C, hw))
-        K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, slope, int(training), gx, gg, gb, ws, B, C, hw, 0)
+        _bn_bwd_into(gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, 0, sync)
         ctx.save_for_backward(gz, x, gamma, beta, mean, invstd)
-        ctx.slope, ctx.training = slope, training
+        ctx.slope, ctx.training, ctx.sync = slope, training, sync
         ctx.set_materialize_grads(False)        # the R1 pass never differentiates ggamma / gbeta: no zero fills for them
         return gx, gg, gb
 
@@ -679,18 +715,31 @@ class _BNActBwd(Function):
         ws = _ws(x, K().bn_workspace(B, C, hw))
         if v is None:
             v = torch.zeros_like(x)
-        K().bn_act_dbwd(v.contiguous(), None if vg is None else vg.contiguous(), None if vb is None else vb.contiguous(),
+        v = v.contiguous()
+        nones = (None,) * 7
+        if ctx.sync is not None:
+            if vg is not None or vb is not None:
+                raise NotImplementedError('synchronised BatchNorm: adjoints of ggamma / gbeta are not propagated '
+                                          '(the R1 penalty differentiates the input gradient only)')
+            sums = _sums(x, C, 5)
+            K().bn_sync_dbwd_local(v, gz, x, mean, invstd, gamma, beta, ctx.slope, sums, ws, B, C, hw)
+            ctx.sync.all_reduce(sums)
+            K().bn_sync_dbwd_finish(v, gz, x, mean, invstd, gamma, beta, ctx.slope, sums, ctx.sync.world * B * hw,
+                                    ctx.sync.world, a_gz, a_x, a_gamma, ws, B, C, hw)
+            return (a_gz, a_x, a_gamma) + nones
+        K().bn_act_dbwd(v, None if vg is None else vg.contiguous(), None if vb is None else vb.contiguous(),
                         gz, x, mean, invstd, gamma, beta, ctx.slope, a_gz, a_x, a_gamma, ws, B, C, hw)
-        return a_gz, a_x, a_gamma, None, None, None, None, None, None
+        return (a_gz, a_x, a_gamma) + nones
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, slope=1.0,
-                   num_batches_tracked=None, replicate=1):
+                   num_batches_tracked=None, replicate=1, sync=None):
     """BatchNorm2d followed by LeakyReLU(slope) in one pass (slope=1: plain BN).  In training mode the
     stats kernel also bumps ``num_batches_tracked`` (int64 device scalar) when given.  ``replicate``: ``x`` stands
-    for a tensor holding every element that many times (see tg_bn_train_stats); only running_var depends on it."""
+    for a tensor holding every element that many times (see tg_bn_train_stats); only running_var depends on it.
+    ``sync``: a ``SyncGroup`` -- batch statistics and backward sums over all ranks' shards (SyncBN)."""
     return _BNAct.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, slope,
-                        num_batches_tracked, replicate)
+                        num_batches_tracked, replicate, sync)
 
 
 # =========================================================================== resampling

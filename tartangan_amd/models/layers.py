@@ -92,14 +92,21 @@ class AvgPool2d(nn.AvgPool2d):
 
 class BatchNorm2d(nn.BatchNorm2d):
     """Train-mode batch statistics or eval-mode running statistics; ``forward_act``
-    fuses the LeakyReLU that follows it in every reference block."""
+    fuses the LeakyReLU that follows it in every reference block.  ``sync_group`` (a ``functional.SyncGroup``, set by
+    ``parallel.DataParallel(sync_bn=True)``; never pickled) makes the training statistics those of the GLOBAL batch."""
+    sync_group = None
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('sync_group', None)          # process-group handles do not travel with a checkpoint
+        return state
 
     def _run(self, x, slope, replicate=1):
         if self.momentum is None or not self.affine or not self.track_running_stats:
             raise NotImplementedError('tartangan_amd.BatchNorm2d: default nn.BatchNorm2d options only')
         return TF.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var,
                                  self.training, self.momentum, self.eps, slope,
-                                 self.num_batches_tracked if self.training else None, replicate)
+                                 self.num_batches_tracked if self.training else None, replicate, self.sync_group)
 
     def forward(self, x):
         return self._run(x, 1.0)

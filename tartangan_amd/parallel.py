@@ -1,39 +1,74 @@
 """Data parallelism for the G+D step: one process per GPU, RCCL over xGMI.
 
-The path shards along the batch (SURVEY.md §8e): every loss is a batch mean, so the global
+The path shards along the batch (SURVEY.md 8e): every loss is a batch mean, so the global
 gradient is the mean of the shard gradients.  Each network's gradients live in ONE flat fp32
-bucket (tartangan_amd.optim), so a step needs exactly two collectives -- all-reduce of the D
-bucket (2.4 MB at 128:3) after the D backward, of the G bucket (5.1 MB) after the G backward --
-issued between the captured HIP graphs of the step.  At these sizes the collectives are
-latency-bound; there is nothing to bucket further.
+bucket (tartangan_amd.optim), so a step needs exactly two gradient collectives -- all-reduce of
+the D bucket (2.4 MB at 128:3) after the D backward, of the G bucket (5.1 MB) after the G backward.
+At these sizes the collectives are latency-bound; there is nothing to bucket further.
 
-BatchNorm uses per-shard batch statistics (not synchronised): an N-GPU run equals the
-reference at the local batch size with averaged gradients, NOT the reference at the global
-batch.  Latents and IQN quantile fractions are drawn as GLOBAL tensors from the same CPU seed
-on every rank and sliced per rank (trainers.trainer.RngFeed), images are sharded by the caller.
+Overlap (``overlap=True``, the default on a device): both all-reduces are issued on a side stream
+that waits for the producing backward, and are joined only where their result is consumed --
+the D bucket right before D's Adam step, i.e. after the G phase's generator forward (which needs
+no discriminator weights; trainers.cnn._g_forward), the G bucket right before G's Adam step, i.e.
+after the host has drawn and uploaded the next step's latents.  The serial schedule
+(``overlap=False``) issues the same collectives on the compute stream; both give bit-identical
+parameters (tests/test_dp_gloo.py).
+
+BatchNorm: with ``sync_bn=True`` every BatchNorm2d of G and D normalises with the statistics of
+the GLOBAL batch (functional.SyncGroup: per-layer all-reduces of the forward / backward /
+second-backward sums), so an N-rank run on B/N images per rank IS the reference at batch B -- what
+BASELINE.json's configs 4 and 5 (batch 256 / 512 over 8 GPUs) need to match the CPU reference.
+With ``sync_bn=False`` statistics are per shard: the run equals the reference at the local batch
+size with averaged gradients (what torch DDP does without SyncBatchNorm), at ~120 fewer small
+collectives per step.  Latents and IQN quantile fractions are drawn as GLOBAL tensors from the
+same CPU seed on every rank and sliced per rank (trainers.trainer.RngFeed); images are sharded by
+the caller.
 """
 import torch
 import torch.distributed as dist
 
 from . import backend as _be
+from . import functional as TF
+from .models.layers import BatchNorm2d
 from .optim import flatten_parameters
 
 
 class DataParallel:
-    def __init__(self, trainer, process_group=None):
+    def __init__(self, trainer, process_group=None, sync_bn=False, overlap=None):
         if not dist.is_initialized():
             raise RuntimeError('init torch.distributed first (backend "nccl" = RCCL on ROCm)')
         self.group = process_group
         self.rank = dist.get_rank(process_group)
         self.world = dist.get_world_size(process_group)
+        self.backend = dist.get_backend(process_group)
         self.trainer = trainer
+        self.sync_bn = bool(sync_bn)
+        on_device = str(trainer.device) != 'cpu'
+        self.overlap = on_device if overlap is None else bool(overlap)
+        self._side = torch.cuda.Stream() if (self.overlap and on_device) else None
+        self._pending = {}
         trainer.data_parallel = self
         feed = trainer.rng_feed
         feed.rank, feed.world = self.rank, self.world
         trainer._route_rng_through_feed()       # IQN taus must come through the feed to be sliced per rank
         if not getattr(trainer, '_graph_requested', False):
             feed.mode = 'off'                   # eager: draw (and slice) the global tensors on every call
+        if self.sync_bn and self.world > 1:
+            handle = TF.SyncGroup(process_group, self.world)
+            for net in (trainer.g, trainer.d):
+                for m in net.modules():
+                    if isinstance(m, BatchNorm2d):
+                        m.sync_group = handle
         self.sync_state()
+
+    @property
+    def collective_name(self):
+        return {'nccl': 'RCCL', 'gloo': 'gloo'}.get(self.backend, self.backend)
+
+    @property
+    def capturable(self):
+        """May a step with in-graph collectives (SyncBN) be captured into HIP graphs?  Only RCCL enqueues device work."""
+        return not (self.sync_bn and self.world > 1) or self.backend == 'nccl'
 
     def sync_state(self):
         """Make every rank start from rank 0's parameters and buffers."""
@@ -43,11 +78,32 @@ class DataParallel:
             for buf in module.buffers():
                 dist.broadcast(buf, src=0, group=self.group)
 
-    def all_reduce_mean(self, flat_grads):
-        if self.world == 1:
-            return
+    # ------------------------------------------------------------------ gradient averaging
+    def _reduce_now(self, flat_grads):
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=self.group)
         _be.get().scale(flat_grads, 1.0 / self.world, flat_grads, flat_grads.numel())
+
+    def all_reduce_mean(self, flat_grads):
+        """Blocking form (serial schedule)."""
+        if self.world > 1:
+            self._reduce_now(flat_grads)
+
+    def begin_all_reduce(self, key, flat_grads):
+        """Start averaging ``flat_grads`` over the ranks; ``finish_all_reduce(key)`` must run before anything reads
+        them.  With a side stream the collective runs beside whatever the compute stream does in between."""
+        if self.world == 1:
+            return
+        if self._side is None:
+            self._reduce_now(flat_grads)
+            return
+        self._side.wait_stream(torch.cuda.current_stream())      # after the backward that produced the bucket
+        with torch.cuda.stream(self._side):
+            self._reduce_now(flat_grads)
+        self._pending[key] = flat_grads
+
+    def finish_all_reduce(self, key):
+        if self._pending.pop(key, None) is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def shard(self, global_batch):
         """Rows of a globally-seeded batch that belong to this rank."""

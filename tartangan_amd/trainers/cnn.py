@@ -116,23 +116,34 @@ class CNNTrainer(Trainer):
                 torch.autograd.backward(d_loss, inputs=[p for p in self.d.parameters() if p.requires_grad])
         return d_loss.detach(), (d_grad_penalty.detach() if d_grad_penalty is not None else None)
 
-    def _g_phase(self, bs):
-        """Generator half up to and including g_loss.backward() (cnn.py:139-148)."""
+    def _g_forward(self, bs):
+        """First part of the generator half (cnn.py:139-143): the generator's forward pass.  It reads no discriminator
+        weight, so in a data-parallel run it is issued BEFORE the discriminator's optimiser step and hides the
+        all-reduce of the discriminator's gradient bucket (same numbers: nothing here depends on that step)."""
         toggle_grad(self.g, True)
         toggle_grad(self.d, False)
         self.optimizer_g.zero_grad()
-        fake = self.sample_g(bs)
+        return self.sample_g(bs)
+
+    def _g_backward(self, fake):
+        """Second part (cnn.py:144-148): D(fake) with the stepped discriminator, the loss, g_loss.backward()."""
         with TF.filter_forms():
-            g_loss = self._g_loss(fake, torch.ones(bs, 1, device=self.device))
+            g_loss = self._g_loss(fake, torch.ones(len(fake), 1, device=self.device))
             with TF.deferred_wgrad():
                 g_loss.backward()
         return g_loss.detach()
+
+    def _g_phase(self, bs):
+        """Generator half up to and including g_loss.backward() (cnn.py:139-148)."""
+        return self._g_backward(self._g_forward(bs))
 
     def train_batch(self, imgs):
         imgs = imgs.to(self.device)
         self.g.train()
         self.d.train()
-        if getattr(self, '_graphs', None) is not None or getattr(self, '_graph_requested', False):
+        dp = self.data_parallel
+        graphs_ok = dp is None or dp.capturable      # SyncBN over gloo: host-side collectives inside the passes
+        if graphs_ok and (getattr(self, '_graphs', None) is not None or getattr(self, '_graph_requested', False)):
             vals = self._train_batch_graphed(imgs)
         else:
             vals = self._train_batch_eager(imgs)
@@ -142,19 +153,22 @@ class CNNTrainer(Trainer):
 
     def _train_batch_eager(self, imgs):
         d_loss, d_grad_penalty = self._d_phase(imgs)
-        self._reduce_gradients(self.optimizer_d)
+        self._begin_reduce('d', self.optimizer_d)          # D-bucket all-reduce under the generator forward below
+        fake = self._g_forward(len(imgs))
+        self._finish_reduce('d')
         self.optimizer_d.step()
-        g_loss = self._g_phase(len(imgs))
-        self._reduce_gradients(self.optimizer_g)
+        g_loss = self._g_backward(fake)
+        self._begin_reduce('g', self.optimizer_g)
+        self._finish_reduce('g')
         self.optimizer_g.step()
         self.update_target_generator()
         return g_loss, d_loss, d_grad_penalty
 
     # ------------------------------------------------------------------ HIP-graph replay of the step
     def enable_graphs(self):
-        """Replay the step from three captured HIP graphs (D phase | D Adam + G phase | G Adam + EMA)
-        instead of ~1500 eager launches.  The cuts are where a data-parallel run all-reduces its
-        gradient buckets.  Host-side RNG is pre-drawn by ``RngFeed`` in the reference's order, so
+        """Replay the step from captured HIP graphs (D phase | G forward | D Adam + D(fake) + G backward |
+        G Adam + EMA; the middle two are one graph on a single GPU) instead of ~1500 eager launches.  The
+        cuts are where a data-parallel run starts / joins the all-reduces of its gradient buckets.  Host-side RNG is pre-drawn by ``RngFeed`` in the reference's order, so
         results are identical to eager mode.  The first call runs eagerly (recording the RNG plan),
         the second captures, later calls only replay."""
         if self.device == 'cpu':
@@ -177,20 +191,29 @@ class CNNTrainer(Trainer):
         self._static_imgs = imgs.clone()
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
-        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        g1, g2a, g2b, g3 = (torch.cuda.CUDAGraph() for _ in range(4))
         # with a process group alive, its watchdog thread polls events; only this thread's calls matter here
         kw = dict(pool=pool)
-        if self.data_parallel is not None and self.data_parallel.world > 1:
+        split = self.data_parallel is not None and self.data_parallel.world > 1
+        if split:
             kw['capture_error_mode'] = 'thread_local'
         with torch.cuda.graph(g1, **kw):
             self._out_d = self._d_phase(self._static_imgs)
-        with torch.cuda.graph(g2, **kw):
-            self.optimizer_d.apply()
-            self._out_g = self._g_phase(len(imgs))
+        if split:           # the generator forward in a graph of its own: it runs while the D bucket is all-reduced
+            with torch.cuda.graph(g2a, **kw):
+                fake = self._g_forward(len(imgs))
+            with torch.cuda.graph(g2b, **kw):
+                self.optimizer_d.apply()
+                self._out_g = self._g_backward(fake)
+        else:
+            g2a = None
+            with torch.cuda.graph(g2b, **kw):
+                self.optimizer_d.apply()
+                self._out_g = self._g_phase(len(imgs))
         with torch.cuda.graph(g3, **kw):
             self.optimizer_g.apply()
             self.update_target_generator()
-        self._graphs = (g1, g2, g3)
+        self._graphs = (g1, g2a, g2b, g3)
         feed.cursor = 0
 
     def _train_batch_graphed(self, imgs):
@@ -227,21 +250,29 @@ class CNNTrainer(Trainer):
                     return self._train_batch_eager(imgs)       # consumes the values refill() just drew
                 finally:
                     feed.mode = 'off'
-        g1, g2, g3 = self._graphs
+        g1, g2a, g2b, g3 = self._graphs
         self._static_imgs.copy_(imgs, non_blocking=True)
         self.optimizer_d.advance()
         self.optimizer_g.advance()
         g1.replay()
-        self._reduce_gradients(self.optimizer_d)
-        g2.replay()
-        self._reduce_gradients(self.optimizer_g)
+        self._begin_reduce('d', self.optimizer_d)
+        if g2a is not None:
+            g2a.replay()                                       # generator forward beside the D-bucket all-reduce
+        self._finish_reduce('d')
+        g2b.replay()
+        self._begin_reduce('g', self.optimizer_g)
+        self._finish_reduce('g')
         g3.replay()
         return self._out_g, self._out_d[0], self._out_d[1]
 
-    def _reduce_gradients(self, optimizer):
-        """Data-parallel hook: average the flat gradient bucket over ranks (no-op on 1 GPU)."""
+    def _begin_reduce(self, key, optimizer):
+        """Data-parallel hooks: start / join the averaging of a flat gradient bucket over the ranks (no-ops on 1 GPU)."""
         if self.data_parallel is not None:
-            self.data_parallel.all_reduce_mean(optimizer.grads)
+            self.data_parallel.begin_all_reduce(key, optimizer.grads)
+
+    def _finish_reduce(self, key):
+        if self.data_parallel is not None:
+            self.data_parallel.finish_all_reduce(key)
 
     @torch.no_grad()
     def update_target_generator(self, lr=None):

@@ -267,6 +267,77 @@ class Emulator:
         _v(a_x, B, C, HW).copy_(c(r) * Pq - c(gamma * A * r * r / n) * xhat)
         return 0
 
+    # ---- SyncBN protocol (local sums -> all-reduce by the caller -> finish), float64 sums [C][K]
+    def bn_sync_stats_local(self, x, sums, ws, B, C, HW):
+        xv = _v(x, B, C, HW).double()
+        m = xv.mean((0, 2))
+        var = xv.var((0, 2), unbiased=False)
+        sums.view(C, 3).copy_(torch.stack([m, m * m, var], 1))
+        return 0
+
+    def bn_sync_stats_finish(self, sums, world, mean, invstd, rm, rv, nbt, momentum, eps, count_global, replicate, C):
+        if nbt is not None:
+            nbt.add_(1)
+        s = sums.view(C, 3) / world
+        m = s[:, 0]
+        var = (s[:, 2] + (s[:, 1] - m * m)).clamp_min(0)
+        mean.copy_(m.float())
+        invstd.copy_((1 / torch.sqrt(var + eps)).float())
+        if rm is not None:
+            n = float(count_global * replicate)
+            rm.copy_(((1 - momentum) * rm.double() + momentum * m).float())
+            rv.copy_(((1 - momentum) * rv.double() + momentum * var * (n / max(n - 1, 1))).float())
+        return 0
+
+    def bn_sync_bwd_local(self, gz, x, mean, invstd, gamma, beta, slope, sums, ws, B, C, HW):
+        xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
+        gyh = (_v(gz, B, C, HW) * s).double()
+        sums.view(C, 2).copy_(torch.stack([gyh.sum((0, 2)), (gyh * xhat.double()).sum((0, 2))], 1))
+        return 0
+
+    def bn_sync_bwd_finish(self, gz, x, mean, invstd, gamma, beta, slope, local, glob, count_global, gx, gg, gb, ws, B, C, HW,
+                           accumulate):
+        xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
+        gyh = _v(gz, B, C, HW) * s
+        lo, gl = local.view(C, 2), glob.view(C, 2)
+        sb, sg = lo[:, 0].float(), lo[:, 1].float()
+        gg.copy_(gg + sg if accumulate else sg)
+        gb.copy_(gb + sb if accumulate else sb)
+        if gx is not None:
+            k1 = (gl[:, 0] / count_global).float().view(1, C, 1)
+            k2 = (gl[:, 1] / count_global).float().view(1, C, 1)
+            _v(gx, B, C, HW).copy_((gamma * invstd).view(1, C, 1) * (gyh - k1 - xhat * k2))
+        return 0
+
+    def bn_sync_dbwd_local(self, v, gz, x, mean, invstd, gamma, beta, slope, sums, ws, B, C, HW):
+        xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
+        xhat = xhat.double()
+        gyh = (_v(gz, B, C, HW) * s).double()
+        vv = _v(v, B, C, HW).double()
+        cols = [vv.sum((0, 2)), (vv * xhat).sum((0, 2)), gyh.sum((0, 2)), (gyh * xhat).sum((0, 2)), (vv * gyh).sum((0, 2))]
+        sums.view(C, 5).copy_(torch.stack(cols, 1))
+        return 0
+
+    def bn_sync_dbwd_finish(self, v, gz, x, mean, invstd, gamma, beta, slope, glob, count_global, world, a_gz, a_x, a_gamma,
+                            ws, B, C, HW):
+        xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
+        n = float(count_global)
+        c = lambda t: t.float().view(1, C, 1)
+        gyh = _v(gz, B, C, HW) * s
+        vv = _v(v, B, C, HW)
+        S1, S2, S3, S4, S5 = glob.view(C, 5).unbind(1)
+        r, g = invstd.double(), gamma.double()
+        A = S5 - S1 * S3 / n - S2 * S4 / n
+        cg, cv = S4 / n, S2 / n
+        qm = -g * r * (cg * S1 / n + cv * S3 / n)
+        qx = -g * r * (cg * S2 / n + cv * S4 / n)
+        a_gamma.copy_((r * A / world).float())
+        Pv = vv - c(S1 / n) - xhat * c(S2 / n)
+        _v(a_gz, B, C, HW).copy_(c(g * r) * Pv * s)
+        q = -c(g * r) * (c(cg) * vv + c(cv) * gyh)
+        _v(a_x, B, C, HW).copy_(c(r) * (q - c(qm) - xhat * c(qx)) - c(g * A * r * r / n) * xhat)
+        return 0
+
     # ---------------------------------------------------------------- resampling
     def up2x(self, x, y, alpha, BC, H, W):
         _v(y, BC, 2 * H, 2 * W).copy_(alpha * _v(x, BC, H, W).repeat_interleave(2, 1).repeat_interleave(2, 2))
