@@ -44,7 +44,9 @@ def parse():
     p.add_argument('--eager', action='store_true', help='do not replay HIP graphs')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-kernel-timing', action='store_true')
-    p.add_argument('--cpu-batch', type=int, default=16)
+    p.add_argument('--cpu-batch', type=int, default=None, help='batch of the CPU-baseline sample (default: --batch)')
+    p.add_argument('--sync-bn', action='store_true', help='N>1: BatchNorm statistics of the GLOBAL batch (SyncBN)')
+    p.add_argument('--no-overlap', action='store_true', help='N>1: gradient all-reduces on the compute stream')
     p.add_argument('--backend', default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the DP code path)')
     p.add_argument('--share-gpu', action='store_true', help='rehearsal only: every rank uses cuda:0')
     return p.parse_args()
@@ -190,22 +192,40 @@ CONV_FAMILY = {'conv2d_fwd': 'conv_fwd_kernel (fwd)', 'conv2d_dgrad': 'conv_fwd_
                'upconv3x3_dgrad': 'conv_upT_kernel', 'poolconv3x3_fwd': 'conv_upT_kernel'}
 
 
-def cpu_baseline(config, kind, batch):
+def _cpu_sample(config, kind, batch, threads, n):
     from oracle import sagan_cpu as O
     name, _, att = config.partition(':')
-    torch.manual_seed(1234)
-    tr = O.OracleTrainer(name, kind, batch, attention=(int(att),) if att else None)
-    size = tr.cfg.base_size * 2 ** len(tr.cfg.blocks)
-    imgs = torch.rand(batch, 3, size, size) * 2 - 1
-    tr.train_batch(imgs)                       # untimed first step (allocator / thread-pool warm-up)
-    t0 = time.perf_counter()
-    n = 2
-    for _ in range(n):
-        tr.train_batch(imgs)
-    dt = time.perf_counter() - t0
-    return dict(value=round(batch * n / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{n} timed steps (+1 untimed) of the {config} {kind} step at batch {batch} on the host CPU, '
-                       f'oracle/sagan_cpu.py (plain PyTorch CPU fp32)')
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        torch.manual_seed(1234)
+        tr = O.OracleTrainer(name, kind, batch, attention=(int(att),) if att else None)
+        size = tr.cfg.base_size * 2 ** len(tr.cfg.blocks)
+        imgs = torch.rand(batch, 3, size, size) * 2 - 1
+        tr.train_batch(imgs)                       # untimed first step (allocator / thread-pool warm-up)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tr.train_batch(imgs)
+        return batch * n / (time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(prev)
+
+
+def cpu_baseline(config, kind, batch):
+    """The CPU oracle (kind "port": oracle/sagan_cpu.py, plain PyTorch CPU fp32, pinned to the reference by the golden
+    fixtures) timed on this host: the GPU line's own workload and batch on every host thread, and -- for comparison
+    with BASELINE.md's 8-thread survey numbers -- a short 8-thread sample."""
+    cores = torch.get_num_threads()
+    n = 3
+    value = _cpu_sample(config, kind, batch, cores, n)
+    out = dict(value=round(value, 3), unit='images/s', cores=cores, kind='port',
+               sample=f'{n} timed steps (+1 untimed) of the {config} {kind} step at batch {batch} on {cores} host threads, '
+                      f'oracle/sagan_cpu.py (plain PyTorch CPU fp32)')
+    if cores > 8:
+        b8 = min(batch, 16)
+        out['threads_8'] = dict(value=round(_cpu_sample(config, kind, b8, 8, 2), 3), unit='images/s', cores=8,
+                                sample=f'2 timed steps (+1 untimed) at batch {b8} on 8 threads')
+    return out
 
 
 def main():
@@ -233,7 +253,7 @@ def main():
         from tartangan_amd.parallel import DataParallel
         if not a.eager:
             tr.enable_graphs()
-        DataParallel(tr)
+        dp = DataParallel(tr, sync_bn=a.sync_bn, overlap=False if a.no_overlap else None)
     elif not a.eager:
         tr.enable_graphs()
     size = tr.g.max_size
@@ -287,16 +307,21 @@ def main():
             'config': {'workload': f'{a.config} SA-GAN {a.trainer} G+D step (R1 penalty, Adam x2, EMA), '
                                    f'{size}x{size} RGB, batch {a.batch}/GPU, global batch {a.batch * world}',
                        'trainer': a.trainer, 'gan_config': a.config, 'global_batch': a.batch * world,
-                       'parallelism': f'dp{world}' + ('' if world == 1 else ' (local-batch BatchNorm, flat-bucket RCCL all-reduce x2)'),
+                       'parallelism': f'dp{world}' + ('' if world == 1 else
+                                                      f' ({"global-batch (synchronised)" if a.sync_bn else "local-batch"} BatchNorm, '
+                                                      f'flat-bucket {dp.collective_name} all-reduce x2'
+                                                      f'{", D bucket on a side stream under the G forward" if dp.overlap else ""})'),
                        'hip_graphs': not a.eager},
             'final_losses': {k: round(v, 6) for k, v in logs.items()},
         }
         flop_img = FLOP_PER_IMAGE.get(a.config)
         if flop_img and a.trainer == 'cnn':
             tf = flop_img * value / world / 1e12
+            # MODEL FLOPs (the reference formulation's) per second -- the step-level utilisation figure; the
+            # engine executes fewer (16-tap stride-2 forms, composed from-RGB): see executed_conv_tflops below
             out['roofline_step'] = {'bound': 'mfma', 'achieved': round(tf, 3), 'peak': MFMA_F32_PEAK_TFLOPS,
                                     'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                                    'flop_per_image': flop_img}
+                                    'flop_per_image': flop_img, 'flops': 'model (reference formulation)'}
         if agg:
             conv = {k: sum(agg[n][k] for n in CONV_FAMILY if n in agg) for k in ('ms', 'launches', 'flops', 'bytes')}
             ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
@@ -313,8 +338,12 @@ def main():
                                          **({'tflops': round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2)} if d['flops'] else {})}
                                      for k, d in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
             out['kernel_time_ms']['_sum_of_timed_launches'] = round(total, 4)
+        if agg and 'roofline_step' in out:
+            ex = sum(d['flops'] for d in agg.values())
+            out['roofline_step']['executed_flop_per_step'] = ex
+            out['roofline_step']['executed_tflops'] = round(ex / (ms_per_step * 1e-3) / 1e12, 3)
         if not a.no_cpu_baseline and world == 1:       # reported at N = 1 only
-            out['cpu_baseline'] = cpu_baseline(a.config, a.trainer, a.cpu_batch)
+            out['cpu_baseline'] = cpu_baseline(a.config, a.trainer, a.cpu_batch or a.batch)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

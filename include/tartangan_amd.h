@@ -331,6 +331,23 @@ int tg_adam_step(float* p, const float* g, float* m, float* v, const float* hype
 /* update_target_generator (trainers/cnn.py:158-165): t += (p - t) * lr */
 int tg_ema(float* t, const float* p, float lr, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------- FID / Inception-score math
+ * inception_utils.py:97-124 torch_cov, :129-144 sqrt_newton_schulz, :205-235 torch_calculate_frechet_distance,
+ * :239-246 calculate_inception_score -- everything after the (network-less) pooled features / softmax outputs.   */
+/* C (M x N) = alpha * op(A) B + diag * I on the fp32 matrix cores, row-major, 128 x 128 tiles staged by LDS-DMA.
+ * transA: A is (K x M) and A^T is used (the covariance product X_c^T X_c).  The Newton-Schulz step
+ * T = 0.5 (3 I - Z Y) is one call with alpha = -0.5, diag = 1.5.  Needs lda, ldb, K % 4 == 0 and 16-byte aligned
+ * A, B (tg_gemm_big_supported); otherwise TG_EUNSUPPORTED (use tg_gemm).                                          */
+int tg_gemm_big_supported(int M, int N, int K, int lda, int ldb, int transA);
+int tg_gemm_big(const float* A, const float* Bm, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                int transA, float alpha, float diag, void* stream);
+/* X[n][d] -= mean[d]  (torch_cov centres its argument in place, inception_utils.py:120) */
+int tg_center_rows(float* X, const float* mean, int N, int D, void* stream);
+/* out[0] = trace(A), A (D x D) with leading dimension ld */
+int tg_trace(const float* A, float* out, int D, int ld, void* stream);
+/* rows[n] = sum_c p[n][c] * (log p[n][c] - log mean[c])  (the KL term of calculate_inception_score) */
+int tg_is_kl_rows(const float* p, const float* mean, float* rows, int N, int Cn, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,8 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith('.json'))
+    # trainer fixtures are named c<size>...; other fixture files (fid_math.json, ...) have their own loaders
+    return sorted(f[:-5] for f in os.listdir(GOLDEN_DIR) if f.endswith('.json') and f[0] == 'c' and f[1].isdigit())
 
 
 def load_golden(name):

@@ -338,6 +338,32 @@ class Emulator:
         _v(a_x, B, C, HW).copy_(c(r) * (q - c(qm) - xhat * c(qx)) - c(g * A * r * r / n) * xhat)
         return 0
 
+    # ---------------------------------------------------------------- FID / IS math
+    def gemm_big_supported(self, M, N, K, lda, ldb, transA):
+        return int(lda % 4 == 0 and ldb % 4 == 0 and (transA or K % 4 == 0))
+
+    def gemm_big(self, A, B, C, M, N, K, lda, ldb, ldc, transA, alpha, diag):
+        a = A.view(-1)[:(K if transA else M) * lda].view(-1, lda)
+        a = a[:, :M].t() if transA else a[:, :K]
+        r = alpha * (a @ B.view(-1, ldb)[:K, :N])
+        if diag:
+            r = r + diag * torch.eye(M, N)
+        C.view(-1, ldc)[:M, :N].copy_(r)
+        return 0
+
+    def center_rows(self, X, mean, N, D):
+        X.view(N, D).sub_(mean.view(1, D))
+        return 0
+
+    def trace(self, A, out, D, ld):
+        out.copy_(torch.diagonal(A.view(-1, ld)[:D, :D]).double().sum().float())
+        return 0
+
+    def is_kl_rows(self, p, mean, rows, N, Cn):
+        pv = p.view(N, Cn)
+        rows.copy_((pv * (pv.log() - mean.view(1, Cn).log())).sum(1))
+        return 0
+
     # ---------------------------------------------------------------- resampling
     def up2x(self, x, y, alpha, BC, H, W):
         _v(y, BC, 2 * H, 2 * W).copy_(alpha * _v(x, BC, H, W).repeat_interleave(2, 1).repeat_interleave(2, 2))

@@ -57,7 +57,8 @@ def _worker(rank, world, port, kind, global_batch, mode, steps, out):
     gathered = [torch.zeros_like(flat_d) for _ in range(world)]
     dist.all_gather(gathered, flat_d)
     if rank == 0:
-        out.put(dict(losses=vals.tolist(), d=flat_d, g=flat_g, graphed=getattr(tr, '_graphs', None) is not None,
+        out.put(dict(losses=vals.tolist(), d=flat_d.tolist(), g=flat_g.tolist(),      # plain lists: the producer exits
+                     graphed=getattr(tr, '_graphs', None) is not None,
                      replicas_equal=all(torch.equal(gathered[0], t) for t in gathered), rng_after=float(torch.rand(1))))
     dist.barrier()
     dist.destroy_process_group()
@@ -87,8 +88,8 @@ def test_graph_replay_with_side_stream_all_reduce_equals_eager():
     for a, b in zip(eager['losses'], graphed['losses']):
         for x, y in zip(a, b):
             assert abs(x - y) <= 1e-6 * max(1.0, abs(x)), (a, b)
-    assert torch.allclose(eager['d'], graphed['d'], rtol=0, atol=1e-6)
-    assert torch.allclose(eager['g'], graphed['g'], rtol=0, atol=1e-6)
+    assert torch.allclose(torch.tensor(eager['d']), torch.tensor(graphed['d']), rtol=0, atol=1e-6)
+    assert torch.allclose(torch.tensor(eager['g']), torch.tensor(graphed['g']), rtol=0, atol=1e-6)
 
 
 @pytest.mark.parametrize('kind', ['cnn', 'iqn'])
