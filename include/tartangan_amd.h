@@ -348,6 +348,17 @@ int tg_trace(const float* A, float* out, int D, int ld, void* stream);
 /* rows[n] = sum_c p[n][c] * (log p[n][c] - log mean[c])  (the KL term of calculate_inception_score) */
 int tg_is_kl_rows(const float* p, const float* mean, float* rows, int N, int Cn, void* stream);
 
+/* ---------------------------------------------------------------- input pipeline
+ * ImageBytesDataset (image_bytes_dataset.py:12-49) + ToPILImage -> RandomCrop(size) -> ToTensor -> Normalize(.5, .5)
+ * (trainers/trainer.py:69-78) for a whole batch: archive = device-resident uint8 (n_images, H, W, channels) exactly
+ * as np.savez_compressed stores it, index[b] = image of batch row b (device int64), crop_y / crop_x = top-left corner
+ * of the size x size crop per row (device int32, nullable = 0: image size == crop size, where RandomCrop draws nothing).
+ * out (B, channels, size, size) fp32 = ((u8 / 255) - 0.5) / 0.5 in ToTensor's / Normalize's operation order.
+ * The caller guarantees 0 <= index < n_images and crop + size <= H, W.                                            */
+int tg_image_bytes_batch(const uint8_t* archive, const int64_t* index, const int* crop_y /*nullable*/,
+                         const int* crop_x /*nullable*/, float* out, int B, int64_t n_images, int H, int W,
+                         int channels, int size, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,8 @@ LIBRARY = os.path.join(_HERE, 'csrc', 'libtartangan_amd.so')
 _CTYPES = {
     'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p,
     'const uint8_t*': ctypes.c_void_p, 'uint8_t*': ctypes.c_void_p, 'int64_t*': ctypes.c_void_p,
-    'const double*': ctypes.c_void_p, 'double*': ctypes.c_void_p,
+    'const double*': ctypes.c_void_p, 'double*': ctypes.c_void_p, 'const int64_t*': ctypes.c_void_p,
+    'const int*': ctypes.c_void_p,
     'void*': ctypes.c_void_p, 'int': ctypes.c_int, 'int64_t': ctypes.c_int64,
     'size_t': ctypes.c_size_t, 'float': ctypes.c_float, 'const char*': ctypes.c_char_p,
     'const tg_host_i64*': ctypes.c_void_p,          # HOST array (a CPU int64 tensor), not a device pointer

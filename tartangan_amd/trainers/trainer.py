@@ -111,6 +111,29 @@ class Trainer:
     def build_models(self):
         raise NotImplementedError
 
+    # ------------------------------------------------------------------ what the components read (trainer.py:192-216)
+    def get_state(self):
+        return dict(epoch=self.epoch, steps=self.steps)
+
+    def set_state(self, state):
+        for key, value in state.items():
+            setattr(self, key, value)
+
+    @property
+    def run_id(self):
+        return getattr(self.args, 'run_id', None) or 'run'
+
+    @property
+    def output_root(self):
+        return f"{getattr(self.args, 'output', './output')}/{self.run_id}"
+
+    def attach(self, *components):
+        """Give components their back-reference, like ``ComponentContainer.add_components`` (trainer.py:43-50)."""
+        for c in components:
+            c.trainer = self
+            self.components.append(c)
+        return self
+
     def train_batch(self, imgs):
         raise NotImplementedError
 

@@ -338,6 +338,17 @@ class Emulator:
         _v(a_x, B, C, HW).copy_(c(r) * (q - c(qm) - xhat * c(qx)) - c(g * A * r * r / n) * xhat)
         return 0
 
+    # ---------------------------------------------------------------- input pipeline
+    def image_bytes_batch(self, archive, index, oy, ox, out, B, n_images, H, W, channels, size):
+        imgs = archive.view(n_images, H, W, channels)
+        for b in range(B):
+            y0 = int(oy[b]) if oy is not None else 0
+            x0 = int(ox[b]) if ox is not None else 0
+            crop = imgs[int(index[b]), y0:y0 + size, x0:x0 + size]
+            t = crop.permute(2, 0, 1).contiguous().to(torch.float32).div(255)       # ToTensor
+            out.view(B, channels, size, size)[b].copy_(t.sub_(0.5).div_(0.5))          # Normalize(.5, .5)
+        return 0
+
     # ---------------------------------------------------------------- FID / IS math
     def gemm_big_supported(self, M, N, K, lda, ldb, transA):
         return int(lda % 4 == 0 and ldb % 4 == 0 and (transA or K % 4 == 0))
