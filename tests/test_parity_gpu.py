@@ -119,6 +119,54 @@ def test_g_phase_gradients_match_oracle(case):
         assert err <= 6e-3 * float(w.abs().max()) + 1e-5 * total, (name, err, float(w.abs().max()))
 
 
+def _adam_flat(opt, params, key):
+    return torch.cat([opt.state[p][key].reshape(-1) for p in params])
+
+
+@pytest.mark.parametrize('case', ['c32_cnn_b16', 'c32a2_iqn_b8', 'c64a1_cnn_b8', 'c64a1_iqn_b8', 'c128a3_cnn_b4'])
+def test_step2_from_resynchronised_state(case):
+    """Steps >= 2 of a free-running comparison are only sanity-bounded (GAN steps amplify rounding chaotically).  Here
+    step 2 is pinned at the step-1 tolerance instead: the CPU oracle (itself pinned to the reference's steps 1-3 at 2e-5,
+    tests/test_oracle_golden.py) takes step 1, its COMPLETE post-step state -- parameters, BatchNorm buffers, Adam
+    moments and step counts, target generator -- is loaded into the HIP trainer, and both take step 2 on the same
+    images and RNG stream.  1e-4 on the three losses, like step 1; the reference's own step-2 numbers are checked too."""
+    from oracle import sagan_cpu as O
+    fx = load_golden(case)
+    if len(fx['steps']) < 2:
+        pytest.skip('fixture holds one step')
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    ref = O.OracleTrainer(fx['config'], fx['trainer'], fx['batch'], attention=fx['attention'])
+    ref.load(g=procedural_state(ref.g, fx['weight_seed']), target_g=procedural_state(ref.target_g, fx['weight_seed'] + 1),
+             d=procedural_state(ref.d, fx['weight_seed'] + 2))
+    torch.manual_seed(fx['rng_seed'])
+    ref.train_batch(synthetic_images(fx['batch'], fx['size'], fx['img_seed']))
+    rng_state = torch.get_rng_state()
+
+    tr = make_trainer(fx)
+    for mine, theirs in ((tr.g, ref.g), (tr.target_g, ref.target_g), (tr.d, ref.d)):
+        mine.load_state_dict({k: v.detach().clone() for k, v in theirs.items()})
+    for opt, theirs, S in ((tr.optimizer_g, ref.opt_g, ref.g), (tr.optimizer_d, ref.opt_d, ref.d)):
+        params = [v for k, v in S.items() if O.is_param(k)]
+        opt.load_state_dict(dict(step=1, exp_avg=_adam_flat(theirs, params, 'exp_avg').cuda(),
+                                 exp_avg_sq=_adam_flat(theirs, params, 'exp_avg_sq').cuda()))
+    imgs2 = synthetic_images(fx['batch'], fx['size'], fx['img_seed'] + 1)
+    torch.set_rng_state(rng_state)
+    want = ref.train_batch(imgs2)
+    after = float(torch.rand(1))
+    torch.set_rng_state(rng_state)
+    got = tr.train_batch(imgs2)
+    assert float(torch.rand(1)) == after
+    tol = KNIFE_EDGE.get(case, 1e-4)
+    for name in ('g_loss', 'd_loss', 'gp'):
+        assert _close(got[name], want[name], tol), (case, name, got[name], want[name])
+        # (the oracle is pinned to the reference's step 2 at 2e-5 single-threaded in the build container; on this host's
+        # CPU and thread count its free-running step 2 may already sit ~1e-4 away -- the chaos this test sidesteps)
+        assert _close(want[name], fx['steps'][1][name], 5e-3), ('oracle vs reference step 2', name)
+    assert _close(_total_l2(tr.d), fx['steps'][1]['d_l2'], 1e-4)
+    assert _close(_total_l2(tr.g), fx['steps'][1]['g_l2'], 1e-4)
+
+
 def test_forward_pins_and_iqn_tau_exactness():
     """Model-level forward pins from the reference modules + bit-exact tau stream / row mapping."""
     import copy
