@@ -951,6 +951,165 @@ conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy, flo
   }
 }
 
+// ---- the same weight-gradient kernel with LDS-DMA staging (see conv_dma_kernel): the patch and the gy tile of a pixel
+// tile go global -> LDS by buffer_load ... lds, nothing passes through VGPRs, no per-element address / bounds code.
+// Same work split (split, co tile, ci chunk), same accumulation order and the same partial-sum layout as
+// conv_wgrad_kernel, so the two are bit-identical and share the plan, the workspace and the reduce kernels.
+// DB: two LDS buffers, the next pixel tile's DMA flies under this tile's MFMAs (one barrier per tile); used where a
+// workgroup walks several tiles and few workgroups share a CU.  The bias gradient is the sum of the A fragments
+// (every gy value of the tile passes through them exactly once).
+constexpr int WGD_GYQ = 65;                     // chunks per gy row: 256 pixels + one pad chunk (== WG_GYS / 4)
+template <class G, int MTW, int CKW, bool DB>
+__global__ void __launch_bounds__(CT_THREADS)
+conv_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part,
+                      float* __restrict__ bias_part /*nullable: [S][Cout]*/, Shape s, int ntiles, int S) {
+  static_assert(G::NPIX == 256 && WG_GYS == 4 * WGD_GYQ, "256-pixel tiles");
+  using P = DPatch<G>;
+  constexpr int KK = 9, CT = 16 * MTW, NCOL = CKW * KK, NT = (NCOL + 15) / 16;
+  constexpr int PCH = CKW * P::CPC, GCH = CT * WGD_GYQ;
+  constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVG = (GCH + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCH * 4, BUF = PBUF + GCH * 4;
+  constexpr int RED = 4 * MTW * NT * 4 * 64 + 4 * CT;
+  constexpr int LDSF = ((DB ? 2 : 1) * BUF > RED) ? (DB ? 2 : 1) * BUF : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDSF];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, h = lane >> 4;
+  const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CKW;
+  const int split = blockIdx.x;
+  const uint32_t HW = (uint32_t)(s.H * s.W);
+
+  int colbase[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = n * 16 + j;
+    const int ci = col / KK, tap = col % KK;
+    colbase[n] = (col < NCOL) ? (ci * P::CIS + (tap / 3) * P::PWS + (tap % 3)) : 0;
+  }
+  const int lane_b = P::pix(wave * 64) + h;
+  const int lane_a = j * WG_GYS + wave * 64 + h;
+
+  f32x4 acc[MTW][NT];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = (bias_part != nullptr) && (blockIdx.z == 0);
+  float bsum[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) bsum[m] = 0.f;
+
+  const int cvalid = min(CKW, s.Cin - ci0);
+  auto issue = [&](int t, float* buf) {
+    const TileCoord tc = decode_tile<G>(t, s.H, s.W);
+    const char* xb = reinterpret_cast<const char*>(x) + ((int64_t)tc.b0 * s.Cin + ci0) * HW * 4;
+    const int64_t xbytes = ((int64_t)(s.B - tc.b0) * s.Cin - ci0) * HW * 4;
+    const char* gb = reinterpret_cast<const char*>(gy) + ((int64_t)tc.b0 * s.Cout + co0) * HW * 4;
+    const int64_t gbytes = ((int64_t)(s.B - tc.b0) * s.Cout - co0) * HW * 4;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gb), 0, (int)gbytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+      const int e = i * CT_THREADS + threadIdx.x;
+      const int ci = e / P::CPC, rem = e % P::CPC;
+      const int row = rem / P::QR, q = rem % P::QR;
+      const int img = row / P::PH, r = row % P::PH;
+      const int hh = tc.h0 + r - 1, ww = tc.w0 - 4 + 4 * q;
+      const bool ok = (rem < P::RAW / 4) && (ci < cvalid) && (tc.b0 + img < s.B) && (hh >= 0) && (hh < s.H) && (ww >= 0) && (ww < s.W);
+      const uint32_t off = ok ? (__umul24(__umul24(img, s.Cin) + ci, HW) + __umul24(hh, s.W) + ww) << 2 : DMA_OOB;
+      if ((i + 1) * CT_THREADS <= PCH || e < PCH) dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
+    }
+#pragma unroll
+    for (int i = 0; i < NVG; ++i) {
+      const int e = i * CT_THREADS + threadIdx.x;
+      const int co = e / WGD_GYQ, q = e % WGD_GYQ;
+      const int p = 4 * q;
+      const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
+      const int hh = tc.h0 + rem / G::TW, ww = tc.w0 + rem % G::TW;
+      const bool ok = (q < 64) && (co0 + co < s.Cout) && (tc.b0 + img < s.B) && (hh < s.H) && (ww < s.W);
+      const uint32_t off = ok ? (__umul24(__umul24(img, s.Cout) + co, HW) + __umul24(hh, s.W) + ww) << 2 : DMA_OOB;
+      if ((i + 1) * CT_THREADS <= GCH || e < GCH) dma16(rg, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
+    }
+  };
+  auto compute = [&](const float* buf) {
+    const float* pl = buf;
+    const float* gl = buf + PBUF;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      constexpr int PPI = G::TH * G::TW;
+      const int pg = 4 * g;
+      const int goff = ((pg / PPI) * P::PH + (pg % PPI) / G::TW) * P::PWS + (pg % G::TW);
+      float a[MTW], b[NT];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) a[m] = gl[lane_a + m * 16 * WG_GYS + 4 * g];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[n] = pl[colbase[n] + lane_b + goff];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) bsum[m] += a[m];
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+  };
+
+  if constexpr (DB) {
+    if (split < ntiles) issue(split, lds);
+    int buf = 0;
+    for (int t = split; t < ntiles; t += S) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + S < ntiles) issue(t + S, lds + (buf ^ 1) * BUF);
+      compute(lds + buf * BUF);
+      buf ^= 1;
+    }
+  } else {
+    for (int t = split; t < ntiles; t += S) {
+      __syncthreads();                          // everybody is done reading the previous tile
+      issue(t, lds);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(lds);
+    }
+  }
+
+  // cross-wave reduction through LDS (fixed order), one partial per workgroup -- as conv_wgrad_kernel
+  __syncthreads();
+  float* red = lds;
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((wave * MTW + m) * NT + n) * 4 + r) * 64 + lane] = acc[m][n][r];
+  constexpr int PER_WAVE = MTW * NT * 4 * 64;
+  float* bred = lds + 4 * PER_WAVE;               // [wave][CT]
+  if (do_bias) {
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      float v = bsum[m];                          // lane (j = channel, h): this lane's pixels; add the four h groups
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (h == 0) bred[wave * CT + m * 16 + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < PER_WAVE; e += CT_THREADS) {
+    const float v = (red[e] + red[PER_WAVE + e]) + (red[2 * PER_WAVE + e] + red[3 * PER_WAVE + e]);
+    const int l = e & 63, q = e >> 6;
+    const int r = q & 3, n = (q >> 2) % NT, m = (q >> 2) / NT;
+    const int col = n * 16 + (l & 15);
+    const int co = co0 + m * 16 + (l >> 4) * 4 + r;
+    const int ci = ci0 + col / KK, tap = col % KK;
+    if (col < NCOL && co < s.Cout && ci < s.Cin)
+      part[(((int64_t)split * s.Cout + co) * s.Cin + ci) * KK + tap] = v;
+  }
+  if (do_bias && threadIdx.x < CT && co0 + (int)threadIdx.x < s.Cout) {
+    const int c = threadIdx.x;
+    bias_part[(int64_t)split * s.Cout + co0 + c] = (bred[c] + bred[CT + c]) + (bred[2 * CT + c] + bred[3 * CT + c]);
+  }
+}
+
 // gw[e] (+)= sum_s part[s][e], fixed order.  64 consecutive e per workgroup (coalesced), the S partials
 // are split over the 4 waves and combined through LDS: no serial chain of S dependent loads.
 // Workgroups past ceil(E/64) reduce the bias partials the same way.
@@ -1622,10 +1781,12 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, const floa
 
 // ---- LDS-DMA kernel dispatch.  Tuning knobs are read once from the environment (development only; the defaults are the
 // measured best): TG_CONV_DMA=0 disables the kernel, TG_DMA_TILE=256|512 and TG_DMA_CK=4|8 force a tile / chunk size.
-struct DmaKnobs { int enable, tile, ck, ksplit; };
+struct DmaKnobs { int enable, tile, ck, ksplit, wgrad, wgrad_db; };
 static const DmaKnobs& dma_knobs() {
   static const DmaKnobs k = [] {
-    DmaKnobs d{1, 0, 0, 1};
+    DmaKnobs d{1, 0, 0, 1, 1, 0};
+    if (const char* e = getenv("TG_DMA_WGRAD")) d.wgrad = atoi(e);
+    if (const char* e = getenv("TG_DMA_WGRAD_DB")) d.wgrad_db = atoi(e);
     if (const char* e = getenv("TG_DMA_KSPLIT")) d.ksplit = atoi(e);
     if (const char* e = getenv("TG_CONV_DMA")) d.enable = atoi(e);
     if (const char* e = getenv("TG_DMA_TILE")) d.tile = atoi(e);
@@ -1738,6 +1899,40 @@ template <class G, int KS>
 int launch_wgrad_geo(const float* x, const float* gy, float* part, float* bias_part, Shape s, const WgPlan& p, hipStream_t st) {
   dim3 grid(p.S, p.co_tiles, p.ci_chunks);
   const int vx = plane_vec_ok(x, s.W), vg = plane_vec_ok(gy, s.W);
+  if constexpr (KS == 3 && G::NPIX == 256) {
+    // LDS-DMA staging: needs whole 16-byte chunks (W % 4, aligned planes) and 32-bit buffer offsets
+    const DmaKnobs& k = dma_knobs();
+    const bool small = (int64_t)s.B * (s.Cin > s.Cout ? s.Cin : s.Cout) * s.H * s.W * 4 < (1ll << 31);
+    constexpr int CKW = WgCfg<3>::CKW;
+    constexpr int buf1 = (CKW * DPatch<G>::CPC + 16 * WGD_GYQ) * 16, buf2 = (CKW * DPatch<G>::CPC + 32 * WGD_GYQ) * 16;   // bytes, MTW 1 / 2
+    if (k.enable && k.wgrad && vx && vg && small) {
+      // (two buffers -- the next tile in flight under this tile's MFMAs -- measured slower at every shape of the 128 px step:
+      // they halve the workgroups per CU; kept behind TG_DMA_WGRAD_DB=1 for wider layers)
+      const bool db = k.wgrad_db == 1 || (k.wgrad_db < 0 && p.tiles >= 2 * p.S && (int64_t)p.S * p.co_tiles * p.ci_chunks <= 600);
+      if (s.Cin <= 4 && p.mtw == 1) {
+        // the composed from-RGB layer (3 image channels + the bias channel): 36 (ci, tap) columns, not 144
+        conv_wgrad_dma_kernel<G, 1, 4, false><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S);
+        return tg_launch_status();
+      }
+      if (p.mtw == 2) {
+        if constexpr (2 * buf2 <= 160 * 1024) {
+          if (db) { conv_wgrad_dma_kernel<G, 2, CKW, true><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S); return tg_launch_status(); }
+        }
+        if constexpr (buf2 <= 160 * 1024) {
+          conv_wgrad_dma_kernel<G, 2, CKW, false><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S);
+          return tg_launch_status();
+        }
+      } else {
+        if constexpr (2 * buf1 <= 160 * 1024) {
+          if (db) { conv_wgrad_dma_kernel<G, 1, CKW, true><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S); return tg_launch_status(); }
+        }
+        if constexpr (buf1 <= 160 * 1024) {
+          conv_wgrad_dma_kernel<G, 1, CKW, false><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S);
+          return tg_launch_status();
+        }
+      }
+    }
+  }
   if (p.mtw == 2) conv_wgrad_kernel<G, KS, 2><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S, vx, vg);
   else conv_wgrad_kernel<G, KS, 1><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S, vx, vg);
   return tg_launch_status();

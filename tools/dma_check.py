@@ -32,21 +32,25 @@ for Cin, Cout, H in SHAPES:
     K.conv2d_fwd(x, w, bias, None, y, B, Cin, Cout, H, H, 3)
     K.conv2d_fwd(x, w, None, res, y2, B, Cin, Cout, H, H, 3)
     K.conv2d_dgrad(gy, w, gx, B, Cin, Cout, H, H, 3)
+    gw = torch.empty_like(w); gb = torch.empty_like(bias)
+    ws = torch.empty(K.conv2d_wgrad_workspace(B, Cin, Cout, H, H, 3) // 4 + 4, device='cuda')
+    K.conv2d_wgrad(x, gy, gw, gb, ws, ws.numel() * 4, B, Cin, Cout, H, H, 3, 0)
     torch.cuda.synchronize()
     key = f'{Cin}-{Cout}-{H}'
     fl = 2.0 * B * Cin * Cout * H * H * 9
     t1 = timeit(lambda: K.conv2d_fwd(x, w, bias, None, y, B, Cin, Cout, H, H, 3))
     t2 = timeit(lambda: K.conv2d_dgrad(gy, w, gx, B, Cin, Cout, H, H, 3))
-    tot += t1 + t2
+    t3 = timeit(lambda: K.conv2d_wgrad(x, gy, gw, gb, ws, ws.numel() * 4, B, Cin, Cout, H, H, 3, 0))
+    tot += t1 + t2 + t3
     msg = ''
     if mode == 'save':
-        ref[key] = (y.cpu(), y2.cpu(), gx.cpu())
+        ref[key] = (y.cpu(), y2.cpu(), gx.cpu(), gw.cpu(), gb.cpu())
     else:
-        for name, got, want in zip(('fwd', 'fwd+res', 'dgrad'), (y, y2, gx), ref[key]):
+        for name, got, want in zip(('fwd', 'fwd+res', 'dgrad', 'wgrad', 'bgrad'), (y, y2, gx, gw, gb), ref[key]):
             want = want.cuda()
             d = (got - want).abs().max().item()
             msg += f' {name}: {"bit-equal" if torch.equal(got, want) else f"max|d| {d:.2e} (ref max {want.abs().max().item():.1f})"};'
-    print(f'{Cin:4d}->{Cout:4d} @{H:3d}^2  fwd {t1:7.1f} us ({fl / t1 / 1e6:5.1f} TF)  dgrad {t2:7.1f} us ({fl / t2 / 1e6:5.1f} TF) {msg}', flush=True)
+    print(f'{Cin:4d}->{Cout:4d} @{H:3d}^2  fwd {t1:7.1f} us ({fl / t1 / 1e6:5.1f} TF)  dgrad {t2:7.1f} us ({fl / t2 / 1e6:5.1f} TF)  wgrad {t3:7.1f} us ({fl / t3 / 1e6:5.1f} TF) {msg}', flush=True)
 print(f'sum {tot:.1f} us')
 if mode == 'save':
     torch.save(ref, path)
