@@ -1538,6 +1538,303 @@ conv_upT_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, con
   Core::epilogue(acc, bias, residual, ga, s, tc, co0, pix0, j, h, wave);
 }
 
+// ---- the two stride-2 kernels with LDS-DMA staging (the scheme of conv_dma_kernel: whole 16-byte chunks, bounds-checked
+// zero padding, filter rows copied as they lie, two LDS buffers, one barrier per channel chunk).  Same arithmetic and
+// accumulation order as conv_upT_kernel / conv_upfwd_kernel.
+template <class G> struct DPatch2x {            // high-resolution windows of a low-resolution tile, rows of 2 TW + 8 floats
+  static constexpr int PH = 2 * G::TH + 2, PWS = 2 * G::TW + 8, QR = PWS / 4;
+  static constexpr int IMG = PH * PWS, RAW = G::NI * IMG;
+  static constexpr int CIS = RAW + ((48 - RAW % 32) % 32);
+  static constexpr int CPC = CIS / 4;
+  static constexpr int PPI = G::TH * G::TW;
+  __device__ __forceinline__ static int pix(int p) {             // top-left tap (row 2r - 1, column 2c - 1) of low-res pixel p
+    const int img = p / PPI, rem = p % PPI;
+    return img * IMG + 2 * (rem / G::TW) * PWS + 2 * (rem % G::TW) + 3;
+  }
+};
+
+// WK (64-pixel tiles): the four waves share the pixels, wave w takes k-group w of every 16-channel chunk.
+template <class G, bool WK>
+__global__ void __launch_bounds__(CT_THREADS)
+conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, const float* __restrict__ bias,
+                    const float* __restrict__ residual, float* __restrict__ ga, Shape s /*Cin = gy channels, Cout = ga channels,
+                    H x W = ga plane*/, int xcd_swizzle) {
+  constexpr int CT = 16, NT = 4, KG = 4, KK = 16, CK = WK ? 16 : 4;
+  using P = DPatch2x<G>;
+  using Core = FwdCore<G, 3, 16, 1, WK>;
+  constexpr int RS = CK * KK + 4, QW = RS / 4;
+  constexpr int PCH = CK * P::CPC, WCH = CT * QW;
+  constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVW = (WCH + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCH * 4, BUF = PBUF + WCH * 4;
+  constexpr int REDF = WK ? 4 * NT * 4 * 64 : 0;
+  __shared__ __attribute__((aligned(16))) float lds[(2 * BUF > REDF) ? 2 * BUF : REDF];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, h = lane >> 4;
+  int bid = blockIdx.x;
+  if (xcd_swizzle) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const TileCoord tc = decode_tile<G>(bid, s.H, s.W);
+  const int co0 = blockIdx.y * CT;
+  const int pix0 = WK ? 0 : wave * 64;
+  const int k0 = WK ? wave * KG : 0;
+  const int H2 = 2 * s.H, W2 = 2 * s.W;
+  const uint32_t HW2 = (uint32_t)(H2 * W2);
+
+  uint32_t poff[NVP], woff[NVW];
+#pragma unroll
+  for (int i = 0; i < NVP; ++i) {
+    const int e = i * CT_THREADS + threadIdx.x;
+    const int ci = e / P::CPC, rem = e % P::CPC;
+    const int row = rem / P::QR, q = rem % P::QR;
+    const int img = row / P::PH, r = row % P::PH;
+    const int hh = 2 * tc.h0 - 1 + r, ww = 2 * tc.w0 - 4 + 4 * q;
+    const bool ok = (e < PCH) && (rem < P::RAW / 4) && (tc.b0 + img < s.B) && (hh >= 0) && (hh < H2) && (ww >= 0) && (ww < W2);
+    poff[i] = ok ? (__umul24(__umul24(img, s.Cin) + ci, HW2) + __umul24(hh, W2) + ww) << 2 : DMA_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < NVW; ++i) {
+    const int e = i * CT_THREADS + threadIdx.x;
+    const int row = e / QW, q = e % QW;
+    const bool ok = (e < WCH) && (4 * q < CK * KK) && (co0 + row < s.Cout);
+    woff[i] = ok ? (uint32_t)(row * s.Cin * KK + 4 * q) << 2 : DMA_OOB;
+  }
+  const char* xb = reinterpret_cast<const char*>(gy) + ((int64_t)tc.b0 * s.Cin * HW2) * 4;
+  int64_t xbytes = (int64_t)(s.B - tc.b0) * s.Cin * HW2 * 4;
+  const int64_t xstep = (int64_t)CK * HW2 * 4;
+  const char* wb = reinterpret_cast<const char*>(w4t) + (int64_t)co0 * s.Cin * KK * 4;
+  int64_t wbytes = (int64_t)(s.Cout - co0) * s.Cin * KK * 4;
+  const int64_t wstep = (int64_t)CK * KK * 4;
+  auto issue = [&](int c0, float* buf) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wb), 0, (int)wbytes, 0x00020000);
+    const int cvalid = s.Cin - c0;
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+      uint32_t off = poff[i];
+      if (cvalid < CK) off = ((i * CT_THREADS + (int)threadIdx.x) / P::CPC < cvalid) ? off : DMA_OOB;
+      if ((i + 1) * CT_THREADS <= PCH || i * CT_THREADS + (int)threadIdx.x < PCH) dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
+    }
+#pragma unroll
+    for (int i = 0; i < NVW; ++i) {
+      uint32_t off = woff[i];
+      if (cvalid < CK) off = (4 * ((i * CT_THREADS + (int)threadIdx.x) % QW) < cvalid * KK) ? off : DMA_OOB;
+      if ((i + 1) * CT_THREADS <= WCH || i * CT_THREADS + (int)threadIdx.x < WCH) dma16(rw, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
+    }
+    xb += xstep; xbytes -= xstep;
+    wb += wstep; wbytes -= wstep;
+  };
+  int lane_b[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) lane_b[n] = (h + k0) * P::CIS + P::pix(pix0 + n * 16 + j);
+  const int lane_a = j * RS + (h + k0) * KK;
+  typename Core::acc_t acc[1][NT];
+  Core::zero(acc);
+
+  issue(0, lds);
+  int buf = 0;
+  for (int c0 = 0; c0 < s.Cin; c0 += CK) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c0 + CK < s.Cin) issue(c0 + CK, lds + (buf ^ 1) * BUF);
+    const float* pl = lds + buf * BUF;
+    const float* wl = pl + PBUF;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float a = wl[lane_a + t];
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[lane_b[n] + (t >> 2) * P::PWS + (t & 3)], acc[0][n], 0, 0, 0);
+    }
+    buf ^= 1;
+  }
+  if constexpr (WK) {
+    __syncthreads();
+    float* red = lds;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * NT + n) * 4 + r) * 64 + lane] = acc[0][n][r];
+    __syncthreads();
+    constexpr int PW_ = NT * 4 * 64;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = (n * 4 + r) * 64 + lane;
+        acc[0][n][r] = (red[e] + red[PW_ + e]) + (red[2 * PW_ + e] + red[3 * PW_ + e]);
+      }
+  }
+  Core::epilogue(acc, bias, residual, ga, s, tc, co0, pix0, j, h, wave);
+}
+
+template <class G, bool WK>
+__global__ void __launch_bounds__(CT_THREADS)
+conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+                      const float* __restrict__ residual, float* __restrict__ y, Shape s, int xcd_swizzle) {
+  constexpr int CT = 16, NT = 4, KG = 4, KK = 4, CK = WK ? 32 : 8, NG = CK / KG, GSTEP = WK ? 4 : 1;
+  using P = DPatch<G>;
+  constexpr int RS = CK * KK + 4, QW = RS / 4, WSZ = CT * RS;        // one phase's filter image
+  constexpr int PCH = CK * P::CPC, WCH = 4 * CT * QW;
+  constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVW = (WCH + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCH * 4, BUF = PBUF + WCH * 4;
+  constexpr int REDF = WK ? 4 * 2 * NT * 4 * 64 : 0;
+  __shared__ __attribute__((aligned(16))) float lds[(2 * BUF > REDF) ? 2 * BUF : REDF];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, h = lane >> 4;
+  int bid = blockIdx.x;
+  if (xcd_swizzle) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const TileCoord tc = decode_tile<G>(bid, s.H, s.W);
+  const int co0 = blockIdx.y * CT;
+  const int pix0 = WK ? 0 : wave * 64;
+  const int k0 = WK ? wave * KG : 0;
+  const uint32_t HW = (uint32_t)(s.H * s.W);
+  const int64_t phase_floats = (int64_t)s.Cout * s.Cin * KK;
+
+  uint32_t poff[NVP], woff[NVW];
+#pragma unroll
+  for (int i = 0; i < NVP; ++i) {
+    const int e = i * CT_THREADS + threadIdx.x;
+    const int ci = e / P::CPC, rem = e % P::CPC;
+    const int row = rem / P::QR, q = rem % P::QR;
+    const int img = row / P::PH, r = row % P::PH;
+    const int hh = tc.h0 + r - 1, ww = tc.w0 - 4 + 4 * q;
+    const bool ok = (e < PCH) && (rem < P::RAW / 4) && (tc.b0 + img < s.B) && (hh >= 0) && (hh < s.H) && (ww >= 0) && (ww < s.W);
+    poff[i] = ok ? (__umul24(__umul24(img, s.Cin) + ci, HW) + __umul24(hh, s.W) + ww) << 2 : DMA_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < NVW; ++i) {
+    const int e = i * CT_THREADS + threadIdx.x;
+    const int ph = e / (CT * QW), rem = e % (CT * QW);
+    const int row = rem / QW, q = rem % QW;
+    const bool ok = (e < WCH) && (4 * q < CK * KK) && (co0 + row < s.Cout);
+    woff[i] = ok ? (uint32_t)(ph * phase_floats + (int64_t)row * s.Cin * KK + 4 * q) << 2 : DMA_OOB;
+  }
+  const char* xb = reinterpret_cast<const char*>(x) + ((int64_t)tc.b0 * s.Cin * HW) * 4;
+  int64_t xbytes = (int64_t)(s.B - tc.b0) * s.Cin * HW * 4;
+  const int64_t xstep = (int64_t)CK * HW * 4;
+  const char* wb = reinterpret_cast<const char*>(wp) + (int64_t)co0 * s.Cin * KK * 4;
+  int64_t wbytes = 4 * phase_floats * 4 - (int64_t)co0 * s.Cin * KK * 4;
+  const int64_t wstep = (int64_t)CK * KK * 4;
+  auto issue = [&](int c0, float* buf) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wb), 0, (int)wbytes, 0x00020000);
+    const int cvalid = s.Cin - c0;
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+      uint32_t off = poff[i];
+      if (cvalid < CK) off = ((i * CT_THREADS + (int)threadIdx.x) / P::CPC < cvalid) ? off : DMA_OOB;
+      if ((i + 1) * CT_THREADS <= PCH || i * CT_THREADS + (int)threadIdx.x < PCH) dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
+    }
+#pragma unroll
+    for (int i = 0; i < NVW; ++i) {
+      uint32_t off = woff[i];
+      if (cvalid < CK) off = (4 * ((i * CT_THREADS + (int)threadIdx.x) % QW) < cvalid * KK) ? off : DMA_OOB;
+      if ((i + 1) * CT_THREADS <= WCH || i * CT_THREADS + (int)threadIdx.x < WCH) dma16(rw, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
+    }
+    xb += xstep; xbytes -= xstep;
+    wb += wstep; wbytes -= wstep;
+  };
+  int lane_b[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) lane_b[n] = (h + k0) * P::CIS + P::pix(pix0 + n * 16 + j);
+  const int lane_a = j * RS + (h + k0) * KK;
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[ph][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0, lds);
+  int buf = 0;
+  for (int c0 = 0; c0 < s.Cin; c0 += CK) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c0 + CK < s.Cin) issue(c0 + CK, lds + (buf ^ 1) * BUF);
+    const float* pl = lds + buf * BUF;
+    const float* wl = pl + PBUF;
+#pragma unroll
+    for (int gi = 0; gi < NG / GSTEP; ++gi) {
+      const int g = gi * GSTEP;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float b[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b[n] = pl[lane_b[n] + (g * KG) * P::CIS + kh * P::PWS + kw];
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+              const int ty = kh - dy, tx = kw - dx;
+              if (ty < 0 || ty > 1 || tx < 0 || tx > 1) continue;
+              const float a = wl[(dy * 2 + dx) * WSZ + lane_a + (g * KG) * KK + ty * 2 + tx];
+#pragma unroll
+              for (int n = 0; n < NT; ++n)
+                acc[dy * 2 + dx][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[dy * 2 + dx][n], 0, 0, 0);
+            }
+        }
+    }
+    buf ^= 1;
+  }
+  if constexpr (WK) {
+    float* red = lds;
+    constexpr int PW_ = 2 * NT * 4 * 64;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      __syncthreads();
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[wave * PW_ + ((dx * NT + n) * 4 + r) * 64 + lane] = acc[dy * 2 + dx][n][r];
+      __syncthreads();
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        if (n != wave) continue;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = ((dx * NT + n) * 4 + r) * 64 + lane;
+            acc[dy * 2 + dx][n][r] = (red[e] + red[PW_ + e]) + (red[2 * PW_ + e] + red[3 * PW_ + e]);
+          }
+      }
+    }
+  }
+  const int W2 = 2 * s.W;
+  const uint32_t HW2 = (uint32_t)(2 * s.H * W2);
+  const int64_t tile0 = ((((int64_t)tc.b0 * s.Cout + co0) * (2 * s.H) + 2 * tc.h0) * W2 + 2 * tc.w0) * 4;
+  char* ybase = reinterpret_cast<char*>(y) + tile0;
+  const char* rbase = reinterpret_cast<const char*>(residual) + tile0;
+  float bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = bias ? bias[min(co0 + 4 * h + r, s.Cout - 1)] : 0.f;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    if (WK && n != wave) continue;
+    const int p = pix0 + n * 16 + j;
+    const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
+    const int pr = rem / G::TW, pc = rem % G::TW;
+    if (tc.b0 + img >= s.B || tc.h0 + pr >= s.H || tc.w0 + pc >= s.W) continue;
+    const uint32_t lane_off = __umul24(__umul24(img, s.Cout) + 4 * h, HW2) + __umul24(2 * pr, W2) + 2 * pc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (co0 + 4 * h + r >= s.Cout) continue;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const uint32_t off = (lane_off + (uint32_t)r * HW2 + (uint32_t)(dy * W2)) << 2;
+        float2 o = make_float2(acc[dy * 2][n][r] + bv[r], acc[dy * 2 + 1][n][r] + bv[r]);
+        if (residual) {
+          const float2 rr = *reinterpret_cast<const float2*>(rbase + off);
+          o.x += rr.x; o.y += rr.y;
+        }
+        *reinterpret_cast<float2*>(ybase + off) = o;
+      }
+    }
+  }
+}
+
 // The third member of the family: T[o][i][u][v] = sum_{b, r, c} lo[b][o][r][c] * hi[b][i][2r-1+u][2c-1+v], the product both
 // weight gradients reduce to (pooled conv: lo = gy, hi = x; up-conv: lo = a, hi = gy), 16 taps per low-resolution pixel and
 // channel pair instead of 36 for the 3x3 weight gradient on the (materialised) high-resolution pair.  Same scheme as
@@ -1718,9 +2015,24 @@ static inline int64_t s2_min_wgs(GeoId g) { return g == GEO_8 ? 128 : 256; }
   } while (0)
 
 // stride-2 transpose form: 8x8 planes that give fewer than 256 four-image tiles run as single-image K-split tiles
+static bool s2_dma_ok(const void* x, const void* w, const Shape& s, int hi_channels);
+
 static void launch_upT(GeoId g, const float* x, const float* w4, const float* bias, const float* residual, float* y, Shape s,
                        int vx, int vw, hipStream_t st) {
   const int cot = (s.Cout + 15) / 16;
+  if (vx && vw && s2_dma_ok(x, w4, s, s.Cin)) {            // LDS-DMA staged forms
+    if (g == GEO_8 && (int64_t)geo_tiles(g, s.B, s.H, s.W) * cot < 256) {
+      const int t = num_tiles<G8k>(s.B, s.H, s.W);
+      conv_upT_dma_kernel<G8k, true><<<dim3(t, cot), CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
+      return;
+    }
+    const int t = geo_tiles(g, s.B, s.H, s.W);
+    dim3 grid(t, cot);
+    if (g == GEO_8) conv_upT_dma_kernel<G8, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
+    else if (g == GEO_16) conv_upT_dma_kernel<G16, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
+    else conv_upT_dma_kernel<GX, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
+    return;
+  }
   if (g == GEO_8 && (int64_t)geo_tiles(g, s.B, s.H, s.W) * cot < 256) {
     conv_upT_kernel<G8k, true><<<dim3(num_tiles<G8k>(s.B, s.H, s.W), cot), CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, vx, vw);
     return;
@@ -1734,6 +2046,19 @@ static void launch_upT(GeoId g, const float* x, const float* w4, const float* bi
 static void launch_upfwd(GeoId g, const float* x, const float* wp, const float* bias, const float* residual, float* y, Shape s,
                          int vx, int vw, hipStream_t st) {
   const int cot = (s.Cout + 15) / 16;
+  if (vx && vw && s2_dma_ok(x, wp, s, 0)) {
+    if (g == GEO_8 && (int64_t)geo_tiles(g, s.B, s.H, s.W) * cot < 256) {
+      const int t = num_tiles<G8k>(s.B, s.H, s.W);
+      conv_upfwd_dma_kernel<G8k, true><<<dim3(t, cot), CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
+      return;
+    }
+    const int t = geo_tiles(g, s.B, s.H, s.W);
+    dim3 grid(t, cot);
+    if (g == GEO_8) conv_upfwd_dma_kernel<G8, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
+    else if (g == GEO_16) conv_upfwd_dma_kernel<G16, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
+    else conv_upfwd_dma_kernel<GX, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
+    return;
+  }
   if (g == GEO_8 && (int64_t)geo_tiles(g, s.B, s.H, s.W) * cot < 256) {
     conv_upfwd_kernel<G8k, true><<<dim3(num_tiles<G8k>(s.B, s.H, s.W), cot), CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, vx, vw);
     return;
@@ -1781,10 +2106,11 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, const floa
 
 // ---- LDS-DMA kernel dispatch.  Tuning knobs are read once from the environment (development only; the defaults are the
 // measured best): TG_CONV_DMA=0 disables the kernel, TG_DMA_TILE=256|512 and TG_DMA_CK=4|8 force a tile / chunk size.
-struct DmaKnobs { int enable, tile, ck, ksplit, wgrad, wgrad_db; };
+struct DmaKnobs { int enable, tile, ck, ksplit, wgrad, wgrad_db, s2; };
 static const DmaKnobs& dma_knobs() {
   static const DmaKnobs k = [] {
-    DmaKnobs d{1, 0, 0, 1, 1, 0};
+    DmaKnobs d{1, 0, 0, 1, 1, 0, 1};
+    if (const char* e = getenv("TG_DMA_S2")) d.s2 = atoi(e);
     if (const char* e = getenv("TG_DMA_WGRAD")) d.wgrad = atoi(e);
     if (const char* e = getenv("TG_DMA_WGRAD_DB")) d.wgrad_db = atoi(e);
     if (const char* e = getenv("TG_DMA_KSPLIT")) d.ksplit = atoi(e);
@@ -1794,6 +2120,17 @@ static const DmaKnobs& dma_knobs() {
     return d;
   }();
   return k;
+}
+
+// stride-2 kernels: whole 16-byte chunks (the callers checked plane / filter alignment), channel counts that keep filter rows
+// 16-byte aligned (x 16 or x 4 floats per channel pair: always), 32-bit buffer offsets; hi_channels > 0: the input is the
+// high-resolution tensor (4x the plane)
+static bool s2_dma_ok(const void* x, const void* w, const Shape& s, int hi_channels) {
+  const DmaKnobs& k = dma_knobs();
+  if (!k.enable || !k.s2) return false;
+  const int64_t plane = (int64_t)s.H * s.W * (hi_channels ? 4 : 1);
+  if ((int64_t)s.B * s.Cin * plane * 4 >= (1ll << 31) || (int64_t)s.Cin * s.Cout * 64 * 4 >= (1ll << 31)) return false;
+  return s.W % 4 == 0 || hi_channels;        // low-resolution rows of whole chunks (high-resolution rows: 2 W, the caller's vx)
 }
 
 template <class G, int CK, bool DGRAD>
