@@ -15,6 +15,31 @@ import torch
 from . import backend as _be
 
 
+ALIGN = 4      # floats: every parameter starts on a 16-byte boundary of the bucket
+
+
+def param_offsets(params):
+    """-> ([offset of each parameter in floats], bucket length).  Offsets are multiples of 4 floats: the conv kernels fetch
+    filters in 16-byte chunks (LDS-DMA, float4), and a 1- or 3-element parameter in front (the attention gamma, the to-RGB
+    bias) would otherwise knock every later tensor of the network off that alignment.  The padding floats stay zero for
+    ever: zero gradient, so Adam and the EMA leave them alone, and they add nothing to an all-reduce."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+    return offs, off
+
+
+def pack(tensors, like):
+    """Per-parameter tensors -> one bucket-shaped tensor on ``like``'s device (e.g. torch.optim.Adam moments ->
+    ``FusedAdam.load_state_dict``)."""
+    offs, n = param_offsets(tensors)
+    flat = torch.zeros(n, dtype=torch.float32, device=like.device)
+    for t, o in zip(tensors, offs):
+        flat[o:o + t.numel()].copy_(t.reshape(-1))
+    return flat
+
+
 def flatten_parameters(module):
     """Re-home ``module``'s parameters into one flat buffer; returns (flat_params, flat_grads).
 
@@ -29,35 +54,33 @@ def flatten_parameters(module):
     # torch.save(module) / torch.load (the reference's ModelCheckpoint pickles whole models,
     # components/model_checkpoint.py:35-45) all leave parameters that are no longer views of the buckets.
     # Rebuild from the CURRENT parameter (and gradient) values.
-    n = sum(p.numel() for p in params)
+    offs, n = param_offsets(params)
     dev = params[0].device
-    flat = torch.empty(n, dtype=torch.float32, device=dev)
+    flat = torch.zeros(n, dtype=torch.float32, device=dev)
     grads = torch.zeros(n, dtype=torch.float32, device=dev)
-    off = 0
     with torch.no_grad():
-        for p in params:
+        for p, off in zip(params, offs):
             k = p.numel()
             flat[off:off + k].copy_(p.detach().reshape(-1))
             if p.grad is not None:
                 grads[off:off + k].copy_(p.grad.detach().reshape(-1))
             p.data = flat[off:off + k].view(p.shape)
             p.grad = grads[off:off + k].view(p.shape)
-            off += k
     module._tg_flat = (flat, grads)
     return flat, grads
 
 
 def _is_bound(params, flat, grads):
     """Host-side check (pointer compares only) that every parameter / gradient is still the view it was made."""
-    off, fp, gp = 0, flat.data_ptr(), grads.data_ptr()
-    for p in params:
+    offs, n = param_offsets(params)
+    fp, gp = flat.data_ptr(), grads.data_ptr()
+    for p, off in zip(params, offs):
         if p.device != flat.device or p.data_ptr() != fp + 4 * off:
             return False
         g = p.grad
         if g is None or g.data_ptr() != gp + 4 * off or not g.is_contiguous():
             return False
-        off += p.numel()
-    return off == flat.numel()
+    return n == flat.numel()
 
 
 class FusedAdam:

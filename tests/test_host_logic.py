@@ -84,16 +84,24 @@ def test_trainer_matches_reference_fixture(case, single_thread):
 
 
 def test_flat_parameter_views_survive_load_state_dict():
-    fx = load_golden('c32_cnn_b16')
+    from tartangan_amd.optim import param_offsets
+    fx = load_golden('c32a2_cnn_b8')
     tr = make_trainer(fx)
     flat = tr.optimizer_d.flat
     tr.d.load_state_dict(procedural_state(tr.d.state_dict(), 3))
-    off = 0
-    for p in tr.d.parameters():
+    params = list(tr.d.parameters())
+    offs, n = param_offsets(params)
+    assert n == flat.numel() and any(p.numel() % 4 for p in params)       # (the attention gamma: 1 element)
+    for p, off in zip(params, offs):
+        assert off % 4 == 0 and p.data_ptr() % 16 == 0                   # every tensor on a 16-byte boundary
         assert p.data_ptr() == flat[off:].data_ptr()
         assert p.grad.data_ptr() == tr.optimizer_d.grads[off:].data_ptr()
-        off += p.numel()
-    assert off == flat.numel()
+    # the padding stays exactly zero through optimiser steps and the EMA
+    used = torch.zeros(n, dtype=torch.bool)
+    for p, off in zip(params, offs):
+        used[off:off + p.numel()] = True
+    tr.train_batch(synthetic_images(fx['batch'], fx['size'], 1))
+    assert float(tr.optimizer_d.flat[~used].abs().max()) == 0.0 and float(tr.optimizer_d.exp_avg_sq[~used].abs().max()) == 0.0
 
 
 def test_deferred_wgrad_never_reduces_one_gradient_twice_in_a_launch():

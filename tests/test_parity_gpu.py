@@ -120,7 +120,8 @@ def test_g_phase_gradients_match_oracle(case):
 
 
 def _adam_flat(opt, params, key):
-    return torch.cat([opt.state[p][key].reshape(-1) for p in params])
+    from tartangan_amd.optim import pack
+    return pack([opt.state[p][key] for p in params], params[0])
 
 
 @pytest.mark.parametrize('case', ['c32_cnn_b16', 'c32a2_iqn_b8', 'c64a1_cnn_b8', 'c64a1_iqn_b8', 'c128a3_cnn_b4'])
