@@ -167,29 +167,43 @@ CONV_DIMS = {'conv2d_fwd': slice(5, 11), 'conv2d_dgrad': slice(3, 9), 'conv2d_wg
              'conv2d_wgrad_partials': slice(4, 10)}
 
 
-def hbm_traffic_per_launch(a, agg):
-    """HBM bytes per conv fwd/dgrad launch from the committed PMC summary (profiles/r01_hbm_traffic.json: rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, tools/pmc_traffic.sh, corrected as the MI355X guide
-    prescribes).  Counters cannot be collected from inside the timed process, so the number is only reported for the
-    workload it was measured on; otherwise null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic.json')
-    if not (os.path.exists(path) and a.config == '128:3' and a.trainer == 'cnn' and a.batch == 64):
-        return None
-    with open(path) as f:
-        k = json.load(f)['kernels']
-    tot = n = 0
-    for name, kernel in CONV_FAMILY.items():
-        if name in agg and kernel in k:
-            tot += agg[name]['launches'] * k[kernel]['hbm_bytes_per_launch']
-            n += agg[name]['launches']
-    return round(tot / n) if n else None
+TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_hbm_traffic.json')
+
+
+def hbm_traffic_per_launch(a):
+    """HBM bytes per launch of the conv fwd/dgrad family from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes over this same command, tools/pmc_traffic.sh, corrected as the MI355X guide prescribes).  Counters
+    cannot be collected from inside the timed process, so the figure comes from that file -- and only if the file was
+    measured on the kernel source this process runs (sha256 of csrc/conv.hip stamped into it) and on this workload;
+    otherwise null, with the reason beside it.  -> (bytes or None, provenance dict)"""
+    import hashlib
+    import subprocess
+    if not os.path.exists(TRAFFIC_FILE):
+        return None, {'traffic_source': None}
+    with open(TRAFFIC_FILE) as f:
+        k = json.load(f)
+    here = os.path.dirname(os.path.abspath(__file__))
+    sha = hashlib.sha256(open(os.path.join(here, 'tartangan_amd', 'csrc', 'conv.hip'), 'rb').read()).hexdigest()
+    try:
+        blob = subprocess.run(['git', 'hash-object', TRAFFIC_FILE], capture_output=True, text=True, cwd=here).stdout.strip()
+    except Exception:
+        blob = None
+    prov = {'traffic_source': 'profiles/r02_hbm_traffic.json', 'traffic_file_git_blob': blob or None,
+            'traffic_measured_on_conv_hip_sha256': k.get('conv_hip_sha256', '')[:16], 'conv_hip_sha256': sha[:16]}
+    if k.get('conv_hip_sha256') != sha:
+        prov['traffic_note'] = 'stale: csrc/conv.hip changed since the counters were collected'
+        return None, prov
+    if not (a.config == '128:3' and a.trainer == 'cnn' and a.batch == 64):
+        prov['traffic_note'] = 'measured on the default workload only'
+        return None, prov
+    return k['conv_family_fwd_dgrad']['hbm_bytes_per_launch'], prov
 
 
 # the MFMA convolution kernels that produce activations / activation gradients: C-ABI entry point -> kernel name in the
 # PMC summary.  (The stride-2 kernels serve the generator's up-convs and the discriminator's pooled convs.)
-CONV_FAMILY = {'conv2d_fwd': 'conv_fwd_kernel (fwd)', 'conv2d_dgrad': 'conv_fwd_kernel (dgrad)',
-               'upconv3x3_fwd': 'conv_upfwd_kernel', 'poolconv3x3_dgrad': 'conv_upfwd_kernel',
-               'upconv3x3_dgrad': 'conv_upT_kernel', 'poolconv3x3_fwd': 'conv_upT_kernel'}
+CONV_FAMILY = {'conv2d_fwd': 'conv_dma_kernel / conv_fwd_kernel (fwd)', 'conv2d_dgrad': 'conv_dma_kernel / conv_fwd_kernel (dgrad)',
+               'upconv3x3_fwd': 'conv_upfwd_dma_kernel', 'poolconv3x3_dgrad': 'conv_upfwd_dma_kernel',
+               'upconv3x3_dgrad': 'conv_upT_dma_kernel', 'poolconv3x3_fwd': 'conv_upT_dma_kernel'}
 
 
 def _cpu_sample(config, kind, batch, threads, n):
@@ -324,11 +338,13 @@ def main():
                                     'flop_per_image': flop_img, 'flops': 'model (reference formulation)'}
         if agg:
             conv = {k: sum(agg[n][k] for n in CONV_FAMILY if n in agg) for k in ('ms', 'launches', 'flops', 'bytes')}
+            traffic, traffic_prov = hbm_traffic_per_launch(a)
             ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA implicit-GEMM conv family: conv_fwd_kernel (fwd + dgrad), conv_upfwd_kernel, conv_upT_kernel',
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA implicit-GEMM conv family (activations and activation gradients): conv_dma_kernel / '
+                                                          'conv_fwd_kernel (fwd + dgrad), conv_upfwd_dma_kernel, conv_upT_dma_kernel, conv1x1_direct_kernel',
                                'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                               'traffic': hbm_traffic_per_launch(a, agg),
+                               'traffic': traffic, **traffic_prov,
                                'algorithmic_bytes_per_launch': round(conv['bytes'] / conv['launches']),
                                'launches_per_step': conv['launches'],
                                'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),

@@ -351,6 +351,61 @@ struct FwdCore {
                                                   const TileCoord& tc, int co0, int pix0, int j, int h, int wave) {
     const int Wo = s.W * s.os;
     const uint32_t HW = (uint32_t)(s.H * s.os * Wo);            // output plane (os = 2: one phase of an upsampling conv)
+    // ---- wide path: a 4 x 4 transpose inside each lane quad (registers = 4 consecutive channel rows, lanes = 4
+    // consecutive pixels of a row) turns four 4-byte stores per register group into ONE 16-byte store per lane (and the
+    // residual / bias reads likewise): these short-K kernels otherwise end on a store-issue-bound tail
+    // (cdna_hip_programming.md T21).  Needs whole pixel quads in a row (W % 4 == 0, 16-byte aligned planes).
+    constexpr int NRW = WK ? NREG / 4 : NREG;
+    if constexpr (NRW % 4 == 0) {
+      const bool wide = (s.os == 1) && (s.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                        (residual == nullptr || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+      if (wide) {
+        const int q = j & 3;
+        const int64_t tile0w = ((((int64_t)tc.b0 * s.Cout + co0) * s.H + tc.h0) * s.W + tc.w0) * 4;
+        char* ybw = reinterpret_cast<char*>(y) + tile0w;
+        const char* rbw = reinterpret_cast<const char*>(residual) + tile0w;
+        constexpr int NQW = WK ? 4 : 1;
+#pragma unroll
+        for (int qq = 0; qq < NQW; ++qq) {
+          if (WK && qq != wave) continue;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int a4 = 0; a4 < NRW / 4; ++a4) {
+              const int r0 = qq * NRW + 4 * a4;                                   // first register of the group
+              const int row = m * MF + ((MF == 32) ? 8 * (r0 >> 2) : 0) + 4 * h + q;     // this lane's channel after the transpose
+              const bool row_ok = co0 + row < s.Cout;
+              const float bvw = (bias && row_ok) ? bias[co0 + row] : 0.f;
+#pragma unroll
+              for (int n = 0; n < NT; ++n) {
+                float t0 = acc[m][n][r0], t1 = acc[m][n][r0 + 1], t2 = acc[m][n][r0 + 2], t3 = acc[m][n][r0 + 3];
+                {   // lanes differing in bit 0 exchange on the register pairs (0,1), (2,3)
+                  const float x01 = (q & 1) ? t0 : t1, x23 = (q & 1) ? t2 : t3;
+                  const float y01 = __shfl_xor(x01, 1, 64), y23 = __shfl_xor(x23, 1, 64);
+                  if (q & 1) { t0 = y01; t2 = y23; } else { t1 = y01; t3 = y23; }
+                }
+                {   // lanes differing in bit 1 exchange on the pairs (0,2), (1,3)
+                  const float x02 = (q & 2) ? t0 : t2, x13 = (q & 2) ? t1 : t3;
+                  const float y02 = __shfl_xor(x02, 2, 64), y13 = __shfl_xor(x13, 2, 64);
+                  if (q & 2) { t0 = y02; t1 = y13; } else { t2 = y02; t3 = y13; }
+                }
+                const int p = pix0 + n * MF + (j & ~3);                            // first pixel of the quad
+                const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
+                const int pr = rem / G::TW, pc = rem % G::TW;
+                if (!row_ok || tc.b0 + img >= s.B || tc.h0 + pr >= s.H || tc.w0 + pc >= s.W) continue;
+                const uint32_t off = (__umul24(__umul24(img, s.Cout) + row, HW) + __umul24(pr, s.W) + pc) << 2;
+                float4 o = make_float4(t0 + bvw, t1 + bvw, t2 + bvw, t3 + bvw);
+                if (residual) {
+                  const float4 rr = *reinterpret_cast<const float4*>(rbw + off);
+                  o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                }
+                *reinterpret_cast<float4*>(ybw + off) = o;
+              }
+            }
+        }
+        return;
+      }
+    }
     const int64_t tile0 = ((((int64_t)tc.b0 * s.Cout + co0) * (s.H * s.os) + tc.h0 * s.os + s.py) * Wo + tc.w0 * s.os + s.px) * 4;
     char* ybase = reinterpret_cast<char*>(y) + tile0;
     const char* rbase = reinterpret_cast<const char*>(residual) + tile0;
@@ -530,7 +585,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_wa
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
-template <class G, int MF, int MT, int CK, bool DGRAD>
+template <class G, int MF, int MT, int CK, bool DGRAD, bool DB = true>
 __global__ void __launch_bounds__(CT_THREADS)
 conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                 const float* __restrict__ residual, float* __restrict__ y, Shape s, int xcd_swizzle) {
@@ -546,7 +601,9 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
   constexpr int PBUF = PCH * 4, WBUF = WCH * 4;                  // floats; lanes past the last chunk of a region issue no DMA
   constexpr int BUF = PBUF + WBUF;
   constexpr int REDF = WK ? 4 * MT * NT * NREG * 64 : 0;         // cross-wave reduction of the K-split partial sums
-  __shared__ __attribute__((aligned(16))) float lds[(2 * BUF > REDF) ? 2 * BUF : REDF];
+  constexpr int NBUF = DB ? 2 : 1;     // DB = false: one buffer, load -> barrier -> MFMA per chunk; the overlap then comes from the
+                                       // other workgroups of the CU (half the LDS: more of them, and exact occupancy rounds)
+  __shared__ __attribute__((aligned(16))) float lds[(NBUF * BUF > REDF) ? NBUF * BUF : REDF];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % MF, h = lane / MF;
@@ -627,12 +684,18 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
   typename Core::acc_t acc[MT][NT];
   Core::zero(acc);
 
-  issue(0, lds);
+  if (DB) issue(0, lds);
   int buf = 0;
   for (int c0 = 0; c0 < s.Cin; c0 += CK) {
+    if constexpr (!DB) {
+      __syncthreads();                                         // everybody is done reading the previous chunk
+      issue(c0, lds);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMAs of chunk c0 have landed ...
     __syncthreads();                                           // ... and everybody's; everybody is done reading the other buffer
-    if (c0 + CK < s.Cin) issue(c0 + CK, lds + (buf ^ 1) * BUF);
+    if constexpr (DB) {
+      if (c0 + CK < s.Cin) issue(c0 + CK, lds + (buf ^ 1) * BUF);
+    }
     const float* pl = lds + buf * BUF;
     const float* wl = pl + PBUF;
 #pragma unroll
@@ -658,7 +721,7 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
           }
       }
     }
-    buf ^= 1;
+    if (DB) buf ^= 1;
   }
   if constexpr (WK) {
     // sum the four waves' partial accumulators through LDS (fixed order), as conv_fwd_kernel does
@@ -1554,7 +1617,7 @@ template <class G> struct DPatch2x {            // high-resolution windows of a 
 };
 
 // WK (64-pixel tiles): the four waves share the pixels, wave w takes k-group w of every 16-channel chunk.
-template <class G, bool WK>
+template <class G, bool WK, bool DB = true>
 __global__ void __launch_bounds__(CT_THREADS)
 conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t, const float* __restrict__ bias,
                     const float* __restrict__ residual, float* __restrict__ ga, Shape s /*Cin = gy channels, Cout = ga channels,
@@ -1566,8 +1629,8 @@ conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t,
   constexpr int PCH = CK * P::CPC, WCH = CT * QW;
   constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVW = (WCH + CT_THREADS - 1) / CT_THREADS;
   constexpr int PBUF = PCH * 4, BUF = PBUF + WCH * 4;
-  constexpr int REDF = WK ? 4 * NT * 4 * 64 : 0;
-  __shared__ __attribute__((aligned(16))) float lds[(2 * BUF > REDF) ? 2 * BUF : REDF];
+  constexpr int REDF = WK ? 4 * NT * 4 * 64 : 0, NBUF = DB ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[(NBUF * BUF > REDF) ? NBUF * BUF : REDF];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, h = lane >> 4;
   int bid = blockIdx.x;
@@ -1629,12 +1692,18 @@ conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t,
   typename Core::acc_t acc[1][NT];
   Core::zero(acc);
 
-  issue(0, lds);
+  if (DB) issue(0, lds);
   int buf = 0;
   for (int c0 = 0; c0 < s.Cin; c0 += CK) {
+    if constexpr (!DB) {
+      __syncthreads();
+      issue(c0, lds);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (c0 + CK < s.Cin) issue(c0 + CK, lds + (buf ^ 1) * BUF);
+    if constexpr (DB) {
+      if (c0 + CK < s.Cin) issue(c0 + CK, lds + (buf ^ 1) * BUF);
+    }
     const float* pl = lds + buf * BUF;
     const float* wl = pl + PBUF;
 #pragma unroll
@@ -1644,7 +1713,7 @@ conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t,
       for (int n = 0; n < NT; ++n)
         acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[lane_b[n] + (t >> 2) * P::PWS + (t & 3)], acc[0][n], 0, 0, 0);
     }
-    buf ^= 1;
+    if (DB) buf ^= 1;
   }
   if constexpr (WK) {
     __syncthreads();
@@ -1666,7 +1735,7 @@ conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t,
   Core::epilogue(acc, bias, residual, ga, s, tc, co0, pix0, j, h, wave);
 }
 
-template <class G, bool WK>
+template <class G, bool WK, bool DB = true>
 __global__ void __launch_bounds__(CT_THREADS)
 conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
                       const float* __restrict__ residual, float* __restrict__ y, Shape s, int xcd_swizzle) {
@@ -1676,8 +1745,8 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
   constexpr int PCH = CK * P::CPC, WCH = 4 * CT * QW;
   constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVW = (WCH + CT_THREADS - 1) / CT_THREADS;
   constexpr int PBUF = PCH * 4, BUF = PBUF + WCH * 4;
-  constexpr int REDF = WK ? 4 * 2 * NT * 4 * 64 : 0;
-  __shared__ __attribute__((aligned(16))) float lds[(2 * BUF > REDF) ? 2 * BUF : REDF];
+  constexpr int REDF = WK ? 4 * 2 * NT * 4 * 64 : 0, NBUF = DB ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[(NBUF * BUF > REDF) ? NBUF * BUF : REDF];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, h = lane >> 4;
   int bid = blockIdx.x;
@@ -1743,12 +1812,18 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[ph][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0, lds);
+  if (DB) issue(0, lds);
   int buf = 0;
   for (int c0 = 0; c0 < s.Cin; c0 += CK) {
+    if constexpr (!DB) {
+      __syncthreads();
+      issue(c0, lds);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (c0 + CK < s.Cin) issue(c0 + CK, lds + (buf ^ 1) * BUF);
+    if constexpr (DB) {
+      if (c0 + CK < s.Cin) issue(c0 + CK, lds + (buf ^ 1) * BUF);
+    }
     const float* pl = lds + buf * BUF;
     const float* wl = pl + PBUF;
 #pragma unroll
@@ -1774,7 +1849,7 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
             }
         }
     }
-    buf ^= 1;
+    if (DB) buf ^= 1;
   }
   if constexpr (WK) {
     float* red = lds;
@@ -2016,6 +2091,7 @@ static inline int64_t s2_min_wgs(GeoId g) { return g == GEO_8 ? 128 : 256; }
 
 // stride-2 transpose form: 8x8 planes that give fewer than 256 four-image tiles run as single-image K-split tiles
 static bool s2_dma_ok(const void* x, const void* w, const Shape& s, int hi_channels);
+static bool s2_single_buffer();
 
 static void launch_upT(GeoId g, const float* x, const float* w4, const float* bias, const float* residual, float* y, Shape s,
                        int vx, int vw, hipStream_t st) {
@@ -2028,6 +2104,12 @@ static void launch_upT(GeoId g, const float* x, const float* w4, const float* bi
     }
     const int t = geo_tiles(g, s.B, s.H, s.W);
     dim3 grid(t, cot);
+    if (s2_single_buffer()) {
+      if (g == GEO_8) conv_upT_dma_kernel<G8, false, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
+      else if (g == GEO_16) conv_upT_dma_kernel<G16, false, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
+      else conv_upT_dma_kernel<GX, false, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
+      return;
+    }
     if (g == GEO_8) conv_upT_dma_kernel<G8, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
     else if (g == GEO_16) conv_upT_dma_kernel<G16, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
     else conv_upT_dma_kernel<GX, false><<<grid, CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
@@ -2054,6 +2136,12 @@ static void launch_upfwd(GeoId g, const float* x, const float* wp, const float* 
     }
     const int t = geo_tiles(g, s.B, s.H, s.W);
     dim3 grid(t, cot);
+    if (s2_single_buffer()) {
+      if (g == GEO_8) conv_upfwd_dma_kernel<G8, false, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
+      else if (g == GEO_16) conv_upfwd_dma_kernel<G16, false, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
+      else conv_upfwd_dma_kernel<GX, false, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
+      return;
+    }
     if (g == GEO_8) conv_upfwd_dma_kernel<G8, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
     else if (g == GEO_16) conv_upfwd_dma_kernel<G16, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
     else conv_upfwd_dma_kernel<GX, false><<<grid, CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
@@ -2106,10 +2194,11 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, const floa
 
 // ---- LDS-DMA kernel dispatch.  Tuning knobs are read once from the environment (development only; the defaults are the
 // measured best): TG_CONV_DMA=0 disables the kernel, TG_DMA_TILE=256|512 and TG_DMA_CK=4|8 force a tile / chunk size.
-struct DmaKnobs { int enable, tile, ck, ksplit, wgrad, wgrad_db, s2; };
+struct DmaKnobs { int enable, tile, ck, ksplit, wgrad, wgrad_db, s2, db; };
 static const DmaKnobs& dma_knobs() {
   static const DmaKnobs k = [] {
-    DmaKnobs d{1, 0, 0, 1, 1, 0, 1};
+    DmaKnobs d{1, 0, 0, 1, 1, 0, 1, 1};
+    if (const char* e = getenv("TG_DMA_DB")) d.db = atoi(e);
     if (const char* e = getenv("TG_DMA_S2")) d.s2 = atoi(e);
     if (const char* e = getenv("TG_DMA_WGRAD")) d.wgrad = atoi(e);
     if (const char* e = getenv("TG_DMA_WGRAD_DB")) d.wgrad_db = atoi(e);
@@ -2133,18 +2222,23 @@ static bool s2_dma_ok(const void* x, const void* w, const Shape& s, int hi_chann
   return s.W % 4 == 0 || hi_channels;        // low-resolution rows of whole chunks (high-resolution rows: 2 W, the caller's vx)
 }
 
+static bool s2_single_buffer() { return dma_knobs().db == 0; }
+
 template <class G, int CK, bool DGRAD>
 static bool launch_dma_geo(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
   const int64_t tiles = num_tiles<G>(s.B, s.H, s.W);
   const int swz = (tiles % 8 == 0) ? 1 : 0;
   const bool use32 = (s.Cout % 32 == 0) || s.Cout > 48;
   // output-channel tile: as wide as the grid allows (one workgroup per CU at the very least)
+  const bool sb = dma_knobs().db == 0;
   if (use32 && s.Cout > 32 && tiles * ((s.Cout + 63) / 64) >= 512) {
     conv_dma_kernel<G, 32, 2, CK, DGRAD><<<dim3(tiles, (s.Cout + 63) / 64), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
   } else if (use32 && tiles * ((s.Cout + 31) / 32) >= 256) {
-    conv_dma_kernel<G, 32, 1, CK, DGRAD><<<dim3(tiles, (s.Cout + 31) / 32), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
+    if (sb) conv_dma_kernel<G, 32, 1, CK, DGRAD, false><<<dim3(tiles, (s.Cout + 31) / 32), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
+    else conv_dma_kernel<G, 32, 1, CK, DGRAD><<<dim3(tiles, (s.Cout + 31) / 32), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
   } else if (tiles * ((s.Cout + 15) / 16) >= 192) {
-    conv_dma_kernel<G, 16, 1, CK, DGRAD><<<dim3(tiles, (s.Cout + 15) / 16), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
+    if (sb) conv_dma_kernel<G, 16, 1, CK, DGRAD, false><<<dim3(tiles, (s.Cout + 15) / 16), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
+    else conv_dma_kernel<G, 16, 1, CK, DGRAD><<<dim3(tiles, (s.Cout + 15) / 16), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
   } else {
     return false;                      // too few tiles: the K-split variants of conv_fwd_kernel fill the chip better
   }

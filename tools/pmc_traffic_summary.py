@@ -16,7 +16,7 @@ def load(d, counter):
             n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
             n = re.sub(r'^void ', '', n).split('(')[0]
             fam = re.sub(r'<.*', '', n)
-            if fam == 'conv_fwd_kernel':
+            if fam in ('conv_fwd_kernel', 'conv_dma_kernel'):
                 fam += ' (dgrad)' if re.search(r', true>$', n) else ' (fwd)'
             agg[fam][0] += 1
             agg[fam][1] += float(r['Counter_Value'])
@@ -33,6 +33,15 @@ for fam in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 0])[
     wr = sw * 1024 / nw
     out[fam] = {'launches_sampled': nf, 'fetch_bytes_per_launch': round(rd), 'write_bytes_per_launch': round(wr),
                 'hbm_bytes_per_launch': round(rd + wr)}
-print(json.dumps({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 2 --warmup 1',
+import hashlib, os
+here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sha = hashlib.sha256(open(os.path.join(here, 'tartangan_amd', 'csrc', 'conv.hip'), 'rb').read()).hexdigest()
+# the roofline family of bench.py: every kernel that produces activations / activation gradients of a 3x3 or stride-2 conv
+FAMILY = ('conv_fwd_kernel (fwd)', 'conv_fwd_kernel (dgrad)', 'conv_dma_kernel (fwd)', 'conv_dma_kernel (dgrad)', 'conv_upfwd_kernel',
+          'conv_upT_kernel', 'conv_upfwd_dma_kernel', 'conv_upT_dma_kernel', 'conv1x1_direct_kernel')
+fl = sum(out[k]['launches_sampled'] for k in FAMILY if k in out)
+fb = sum(out[k]['launches_sampled'] * out[k]['hbm_bytes_per_launch'] for k in FAMILY if k in out)
+family = {'kernels': [k for k in FAMILY if k in out], 'launches_sampled': fl, 'hbm_bytes_per_launch': round(fb / max(fl, 1))}
+print(json.dumps({'conv_hip_sha256': sha, 'conv_family_fwd_dgrad': family, 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 2 --warmup 1',
                   'corrections': 'KiB -> bytes; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B)',
                   'kernels': dict(list(out.items())[:40])}, indent=1))
