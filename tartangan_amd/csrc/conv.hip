@@ -1882,6 +1882,9 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
   const int64_t tile0 = ((((int64_t)tc.b0 * s.Cout + co0) * (2 * s.H) + 2 * tc.h0) * W2 + 2 * tc.w0) * 4;
   char* ybase = reinterpret_cast<char*>(y) + tile0;
   const char* rbase = reinterpret_cast<const char*>(residual) + tile0;
+  // (the residual add keeps the reference's order: (acc + bias) + residual)
+  const bool wide = (s.W % 2 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0) &&
+                    (residual == nullptr || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
   float bv[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bv[r] = bias ? bias[min(co0 + 4 * h + r, s.Cout - 1)] : 0.f;
@@ -1893,6 +1896,27 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
     const int pr = rem / G::TW, pc = rem % G::TW;
     if (tc.b0 + img >= s.B || tc.h0 + pr >= s.H || tc.w0 + pc >= s.W) continue;
     const uint32_t lane_off = __umul24(__umul24(img, s.Cout) + 4 * h, HW2) + __umul24(2 * pr, W2) + 2 * pc;
+    if (wide) {
+      // lane pairs (two horizontally adjacent low-resolution pixels) trade output rows: the even lane stores the four
+      // columns of row 2 pr, the odd lane those of row 2 pr + 1 -- one 16-byte store per lane instead of two 8-byte ones
+      const int odd = j & 1;
+      const uint32_t off0 = lane_off - (odd ? 2 : 0) + (odd ? (uint32_t)W2 : 0u);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a00 = acc[0][n][r] + bv[r], a01 = acc[1][n][r] + bv[r], a10 = acc[2][n][r] + bv[r], a11 = acc[3][n][r] + bv[r];
+        const float sx = odd ? a00 : a10, sy = odd ? a01 : a11;                 // what the partner needs
+        const float rx = __shfl_xor(sx, 1, 64), ry = __shfl_xor(sy, 1, 64);
+        if (co0 + 4 * h + r >= s.Cout) continue;
+        float4 o = odd ? make_float4(rx, ry, a10, a11) : make_float4(a00, a01, rx, ry);
+        const uint32_t off = (off0 + (uint32_t)r * HW2) << 2;
+        if (residual) {
+          const float4 rr = *reinterpret_cast<const float4*>(rbase + off);
+          o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        *reinterpret_cast<float4*>(ybase + off) = o;
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (co0 + 4 * h + r >= s.Cout) continue;
