@@ -608,7 +608,7 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % MF, h = lane / MF;
   int bid = blockIdx.x;
-  if (xcd_swizzle) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);     // an XCD (block id mod 8) works on neighbouring tiles
+  if (xcd_swizzle & 1) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);     // an XCD (block id mod 8) works on neighbouring tiles
   const TileCoord tc = decode_tile<G>(bid, s.H, s.W);
   const int co0 = blockIdx.y * CT;
   const int pix0 = WK ? 0 : wave * G::PPW;
@@ -698,6 +698,7 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
     }
     const float* pl = lds + buf * BUF;
     const float* wl = pl + PBUF;
+    if (xcd_swizzle & 4) { buf ^= 1; continue; }               // diagnostic build only: no MFMAs
 #pragma unroll
     for (int gi = 0; gi < NG / (WK ? 4 : 1); ++gi) {
       const int g = gi * (WK ? 4 : 1);                           // (+ g0, in the lane bases)
@@ -745,6 +746,7 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
           acc[m][n][r] = (red[e] + red[PW_ + e]) + (red[2 * PW_ + e] + red[3 * PW_ + e]);
         }
   }
+  if ((xcd_swizzle & 2) && acc[0][0][0] != 12345.678f) return;   // diagnostic build only: no epilogue
   Core::epilogue(acc, bias, residual, y, s, tc, co0, pix0, j, h, wave);
 }
 
@@ -2218,10 +2220,11 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, const floa
 
 // ---- LDS-DMA kernel dispatch.  Tuning knobs are read once from the environment (development only; the defaults are the
 // measured best): TG_CONV_DMA=0 disables the kernel, TG_DMA_TILE=256|512 and TG_DMA_CK=4|8 force a tile / chunk size.
-struct DmaKnobs { int enable, tile, ck, ksplit, wgrad, wgrad_db, s2, db; };
+struct DmaKnobs { int enable, tile, ck, ksplit, wgrad, wgrad_db, s2, db, diag; };
 static const DmaKnobs& dma_knobs() {
   static const DmaKnobs k = [] {
-    DmaKnobs d{1, 0, 0, 1, 1, 0, 1, 1};
+    DmaKnobs d{1, 0, 0, 1, 1, 0, 1, 1, 0};
+    if (const char* e = getenv("TG_DMA_DIAG")) d.diag = atoi(e) & 6;
     if (const char* e = getenv("TG_DMA_DB")) d.db = atoi(e);
     if (const char* e = getenv("TG_DMA_S2")) d.s2 = atoi(e);
     if (const char* e = getenv("TG_DMA_WGRAD")) d.wgrad = atoi(e);
@@ -2251,7 +2254,7 @@ static bool s2_single_buffer() { return dma_knobs().db == 0; }
 template <class G, int CK, bool DGRAD>
 static bool launch_dma_geo(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
   const int64_t tiles = num_tiles<G>(s.B, s.H, s.W);
-  const int swz = (tiles % 8 == 0) ? 1 : 0;
+  const int swz = ((tiles % 8 == 0) ? 1 : 0) | dma_knobs().diag;
   const bool use32 = (s.Cout % 32 == 0) || s.Cout > 48;
   // output-channel tile: as wide as the grid allows (one workgroup per CU at the very least)
   const bool sb = dma_knobs().db == 0;
