@@ -149,6 +149,8 @@ class KernelTimer:
                 flops = 2.0 * B * Cin * Cout * H * W * 16
                 hi = Cin if name.startswith('poolconv') else Cout      # channels of the high-resolution (2H x 2W) tensor
                 nbytes = 4.0 * (B * hi * 4 * H * W + B * (Cin + Cout - hi) * H * W + Cin * Cout * 16)
+            if name in ('conv2d_fwd', 'conv2d_dgrad') and args[CONV_DIMS[name]][5] == 1:
+                name = name + '_1x1'         # bandwidth-bound (AI = Cin Cout / (2 (Cin + Cout)) FLOP/B << the MFMA ridge)
             d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             d['ms'] += ms
             d['launches'] += 1
@@ -340,8 +342,8 @@ def main():
             conv = {k: sum(agg[n][k] for n in CONV_FAMILY if n in agg) for k in ('ms', 'launches', 'flops', 'bytes')}
             traffic, traffic_prov = hbm_traffic_per_launch(a)
             ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA implicit-GEMM conv family (activations and activation gradients): conv_dma_kernel / '
-                                                          'conv_fwd_kernel (fwd + dgrad), conv_upfwd_dma_kernel, conv_upT_dma_kernel, conv1x1_direct_kernel',
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA implicit-GEMM 3x3 / stride-2 conv family (activations and activation gradients): '
+                                                          'conv_dma_kernel (fwd + dgrad), conv_upfwd_dma_kernel, conv_upT_dma_kernel',
                                'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                                'traffic': traffic, **traffic_prov,
@@ -349,6 +351,12 @@ def main():
                                'launches_per_step': conv['launches'],
                                'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
                                'algorithmic_flop_per_step': conv['flops']}
+            one = {k: sum(agg[n][k] for n in ('conv2d_fwd_1x1', 'conv2d_dgrad_1x1') if n in agg) for k in ('ms', 'launches', 'bytes')}
+            if one['launches']:          # the 1x1 convolutions are priced against the HBM roof
+                gbs = one['bytes'] / (one['ms'] * 1e-3) / 1e9
+                out['roofline_1x1'] = {'bound': 'hbm', 'kernel': '1x1 convolutions (fwd + dgrad): conv_fwd_kernel<.., 1, ..>, conv1x1_direct_kernel',
+                                       'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                                       'launches_per_step': one['launches'], 'avg_launch_ms': round(one['ms'] / one['launches'], 5)}
             total = sum(d['ms'] for d in agg.values())
             out['kernel_time_ms'] = {k: {'ms': round(d['ms'], 4), 'launches': d['launches'],
                                          **({'tflops': round(d['flops'] / (d['ms'] * 1e-3) / 1e12, 2)} if d['flops'] else {})}

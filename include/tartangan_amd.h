@@ -165,7 +165,7 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma /*nullable*/, const float
                    const float* gz, const float* x, const float* mean, const float* invstd,
                    const float* gamma, const float* beta, float slope,
                    float* adj_gz, float* adj_x, float* adj_gamma, float* workspace,
-                   int B, int C, int HW, void* stream);
+                   int B, int C, int HW, int accumulate /* adj_gamma += */, void* stream);
 
 /* ---- BatchNorm under data parallelism (SyncBN; SURVEY.md 8e collective 3).  The reference normalises over the whole
  * batch (trainers/cnn.py:122-123 evaluates D on all B images); when the batch is sharded over ranks the same numbers
@@ -197,7 +197,7 @@ int tg_bn_sync_dbwd_finish(const float* v, const float* gz, const float* x, cons
                            const float* invstd, const float* gamma, const float* beta, float slope,
                            const double* global_sums /*[C][5], all-reduced*/, int64_t count_global, int world,
                            float* adj_gz, float* adj_x, float* adj_gamma, float* workspace,
-                           int B, int C, int HW, void* stream);
+                           int B, int C, int HW, int accumulate /* adj_gamma += */, void* stream);
 
 /* ---------------------------------------------------------------- resampling
  * F.interpolate(scale_factor=2,'nearest') generator.py:58 and nn.AvgPool2d(2)
@@ -235,6 +235,10 @@ int tg_sum_reps(const float* x, float* out, float alpha, int rows, int cols, int
 
 /* ---------------------------------------------------------------- elementwise */
 int tg_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* out = ((a + b) + c) + d, c / d nullable: the gradient fan-in of a tensor with several consumers (attention.py:22-35: x
+ * feeds theta, phi, g and the residual) in one pass */
+int tg_add4(const float* a, const float* b, const float* c /*nullable*/, const float* d /*nullable*/, float* out,
+            int64_t n, void* stream);
 int tg_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
 int tg_scale(const float* x, float alpha, float* out, int64_t n, void* stream);
 /* out = (alpha * *s) * x, s a device scalar */

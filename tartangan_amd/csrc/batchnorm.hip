@@ -289,7 +289,7 @@ struct RedDbwd {
 // coef: 0 S1/n  1 S2/n  2 cg  3 cv  4 qm  5 qx  6 gamma*A*r^2/n
 __global__ void dbwd_stage2(const double* __restrict__ partial, const float* __restrict__ gamma, const float* __restrict__ invstd,
                             const float* __restrict__ vgamma, float* __restrict__ adj_gamma, float* __restrict__ coef,
-                            int B, int C, int HW, int S) {
+                            int B, int C, int HW, int S, int accumulate) {
   const int c = blockIdx.x;                       // one wave per channel
   const double n = (double)B * HW;
   const double S1 = planes::gather(partial, c, S, 5, 0), S2 = planes::gather(partial, c, S, 5, 1);
@@ -302,7 +302,7 @@ __global__ void dbwd_stage2(const double* __restrict__ partial, const float* __r
   const double cg = S4 / n, cv = S2 / n;
   const double qm = -g * r * (cg * S1 / n + cv * S3 / n) + vg * S3 / n;
   const double qx = -g * r * (cg * S2 / n + cv * S4 / n) + vg * S4 / n;
-  adj_gamma[c] = (float)(r * A);
+  adj_gamma[c] = (float)(r * A) + (accumulate ? adj_gamma[c] : 0.f);
   float* k = coef + c * COEF;
   k[0] = (float)(S1 / n); k[1] = (float)(S2 / n); k[2] = (float)cg; k[3] = (float)cv;
   k[4] = (float)qm; k[5] = (float)qx; k[6] = (float)(g * A * r * r / n);
@@ -467,7 +467,8 @@ __global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restri
                                                            const float* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float slope, float* __restrict__ adj_gz,
-                                                           float* __restrict__ adj_x, float* __restrict__ adj_gamma, int B, int C, int HW) {
+                                                           float* __restrict__ adj_x, float* __restrict__ adj_gamma, int B, int C, int HW,
+                                                           int accumulate) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
   const SmallIdx ix(B, C, HW, c);
@@ -500,7 +501,7 @@ __global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restri
   const float qx = (float)(-g * rd * (cgd * S2 / n + cvd * S4 / n) + vg * S4 / n);
   const float k6 = (float)(g * A * rd * rd / n);
   const float vgf = (float)vg, vbf = vbeta ? vbeta[c] : 0.f;
-  if (threadIdx.x == 0) adj_gamma[c] = (float)(rd * A);
+  if (threadIdx.x == 0) adj_gamma[c] = (float)(rd * A) + (accumulate ? adj_gamma[c] : 0.f);
 #pragma unroll
   for (int i = 0; i < SPER; ++i)
     if (ix.ok[i]) {
@@ -576,7 +577,8 @@ __global__ void sync_bwd_finish(const double* __restrict__ local, const double* 
 // dbwd_stage2 on the global sums; adj_gamma is this rank's 1/world share of r*A (the shares add up to the global adjoint
 // under the gradient all-reduce; see DESIGN.md "SyncBN")
 __global__ void sync_dbwd_finish(const double* __restrict__ global, double count, int world, const float* __restrict__ gamma,
-                                 const float* __restrict__ invstd, float* __restrict__ adj_gamma, float* __restrict__ coef, int C) {
+                                 const float* __restrict__ invstd, float* __restrict__ adj_gamma, float* __restrict__ coef, int C,
+                                 int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double n = count;
@@ -586,7 +588,7 @@ __global__ void sync_dbwd_finish(const double* __restrict__ global, double count
   const double cg = S4 / n, cv = S2 / n;
   const double qm = -g * r * (cg * S1 / n + cv * S3 / n);
   const double qx = -g * r * (cg * S2 / n + cv * S4 / n);
-  adj_gamma[c] = (float)(r * A / (double)world);
+  adj_gamma[c] = (float)(r * A / (double)world) + (accumulate ? adj_gamma[c] : 0.f);
   float* k = coef + c * COEF;
   k[0] = (float)(S1 / n); k[1] = (float)(S2 / n); k[2] = (float)cg; k[3] = (float)cv;
   k[4] = (float)qm; k[5] = (float)qx; k[6] = (float)(g * A * r * r / n);
@@ -694,14 +696,15 @@ int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const floa
 
 int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, const float* gz, const float* x,
                    const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
-                   float* adj_gz, float* adj_x, float* adj_gamma, float* workspace, int B, int C, int HW, void* stream) {
+                   float* adj_gz, float* adj_x, float* adj_gamma, float* workspace, int B, int C, int HW, int accumulate,
+                   void* stream) {
   TG_CHECK_PTR(v); TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma);
   TG_CHECK_PTR(beta); TG_CHECK_PTR(adj_gz); TG_CHECK_PTR(adj_x); TG_CHECK_PTR(adj_gamma); TG_CHECK_PTR(workspace);
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   hipStream_t st = tg_stream(stream);
   if (small_case(B, C, HW) && (int64_t)B * HW <= 4096) {
     bn_small_dbwd_kernel<<<C, SB, 0, st>>>(v, vgamma, vbeta, gz, x, mean, invstd, gamma, beta, slope, adj_gz, adj_x, adj_gamma,
-                                              B, C, HW);
+                                              B, C, HW, accumulate);
     return tg_launch_status();
   }
   Parts p = split_ws(workspace, B, C, HW);
@@ -709,7 +712,7 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, cons
   const bool al = tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(v) && tg_aligned16(adj_gz) && tg_aligned16(adj_x);
   planes::launch_reduce(red, p.partial, B, C, HW, st, al);
   dbwd_stage2<<<C, 64, 0, st>>>(p.partial, gamma, invstd, vgamma, adj_gamma, p.coef, B, C, HW,
-                                           planes::splits(B, C, HW));
+                                           planes::splits(B, C, HW), accumulate);
   DbwdBody body{v, gz, x, adj_gz, adj_x, mean, invstd, gamma, beta, vgamma, vbeta, p.coef, slope};
   planes::launch_map(body, B, C, HW, st, al);
   return tg_launch_status();
@@ -786,7 +789,7 @@ int tg_bn_sync_dbwd_local(const float* v, const float* gz, const float* x, const
 int tg_bn_sync_dbwd_finish(const float* v, const float* gz, const float* x, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, float slope, const double* global_sums, int64_t count_global,
                            int world, float* adj_gz, float* adj_x, float* adj_gamma, float* workspace, int B, int C, int HW,
-                           void* stream) {
+                           int accumulate, void* stream) {
   TG_CHECK_PTR(v); TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma);
   TG_CHECK_PTR(beta); TG_CHECK_PTR(global_sums); TG_CHECK_PTR(adj_gz); TG_CHECK_PTR(adj_x); TG_CHECK_PTR(adj_gamma);
   TG_CHECK_PTR(workspace);
@@ -794,7 +797,7 @@ int tg_bn_sync_dbwd_finish(const float* v, const float* gz, const float* x, cons
   if (count_global <= 0) return TG_EINVAL;
   hipStream_t st = tg_stream(stream);
   Parts p = split_ws(workspace, B, C, HW);
-  sync_dbwd_finish<<<chan_grid(C), 64, 0, st>>>(global_sums, (double)count_global, world, gamma, invstd, adj_gamma, p.coef, C);
+  sync_dbwd_finish<<<chan_grid(C), 64, 0, st>>>(global_sums, (double)count_global, world, gamma, invstd, adj_gamma, p.coef, C, accumulate);
   DbwdBody body{v, gz, x, adj_gz, adj_x, mean, invstd, gamma, beta, nullptr, nullptr, p.coef, slope};
   const bool al = tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(v) && tg_aligned16(adj_gz) && tg_aligned16(adj_x);
   planes::launch_map(body, B, C, HW, st, al);

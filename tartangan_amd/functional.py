@@ -711,7 +711,9 @@ class _BNActBwd(Function):
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         a_gz, a_x = torch.empty_like(x), torch.empty_like(x)
-        a_gamma = x.new_empty(C)
+        sink = _grad_sink(gamma)              # the R1 penalty's contribution to gamma's gradient straight into the bucket
+        a_gamma = x.new_empty(C) if sink is None else sink
+        acc = 0 if sink is None else 1
         ws = _ws(x, K().bn_workspace(B, C, hw))
         if v is None:
             v = torch.zeros_like(x)
@@ -725,11 +727,11 @@ class _BNActBwd(Function):
             K().bn_sync_dbwd_local(v, gz, x, mean, invstd, gamma, beta, ctx.slope, sums, ws, B, C, hw)
             ctx.sync.all_reduce(sums)
             K().bn_sync_dbwd_finish(v, gz, x, mean, invstd, gamma, beta, ctx.slope, sums, ctx.sync.world * B * hw,
-                                    ctx.sync.world, a_gz, a_x, a_gamma, ws, B, C, hw)
-            return (a_gz, a_x, a_gamma) + nones
+                                    ctx.sync.world, a_gz, a_x, a_gamma, ws, B, C, hw, acc)
+            return (a_gz, a_x, a_gamma if sink is None else None) + nones
         K().bn_act_dbwd(v, None if vg is None else vg.contiguous(), None if vb is None else vb.contiguous(),
-                        gz, x, mean, invstd, gamma, beta, ctx.slope, a_gz, a_x, a_gamma, ws, B, C, hw)
-        return (a_gz, a_x, a_gamma) + nones
+                        gz, x, mean, invstd, gamma, beta, ctx.slope, a_gz, a_x, a_gamma, ws, B, C, hw, acc)
+        return (a_gz, a_x, a_gamma if sink is None else None) + nones
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, slope=1.0,
@@ -1037,6 +1039,49 @@ class _Add(Function):
 
 def add(a, b):
     return _Add.apply(a, b)
+
+
+class _SumN(Function):
+    """((a + b) + c) + d for 2-4 same-shaped tensors in one kernel."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        ts = [t.contiguous() for t in ts]
+        out = torch.empty_like(ts[0])
+        c = ts[2] if len(ts) > 2 else None
+        d = ts[3] if len(ts) > 3 else None
+        K().add4(ts[0], ts[1], c, d, out, out.numel())
+        ctx.n = len(ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) * ctx.n
+
+
+class _ForkN(Function):
+    """x -> n aliases of x, one graph node: its backward sees all n incoming gradients at once and adds them in ONE kernel
+    (tg_add4) instead of the autograd engine's n - 1 separate adds.  For a tensor with several consumers inside a block
+    (SelfAttention2d: theta, phi, g and the residual all read x)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        return _SumN.apply(*gs), None
+
+
+def fork(x, n):
+    """-> n tensors equal to x whose gradients are summed by one kernel (2 <= n <= 4)."""
+    return _ForkN.apply(x, n)
 
 
 class _Mul(Function):

@@ -29,8 +29,12 @@ class SelfAttention2d(nn.Module):
     def forward(self, x, y=None):
         b, c, h, w = x.shape
         n = h * w
-        theta = self.theta(x).view(b, c // 8, n)
-        phi = TF.max_pool2(self.phi(x)).view(b, c // 8, n // 4)
-        g = TF.max_pool2(self.g(x)).view(b, c // 2, n // 4)
+        if x.requires_grad and torch.is_grad_enabled():
+            xt, xp, xg, xr = TF.fork(x, 4)       # four consumers: their gradients meet in one kernel, not three autograd adds
+        else:
+            xt = xp = xg = xr = x
+        theta = self.theta(xt).view(b, c // 8, n)
+        phi = TF.max_pool2(self.phi(xp)).view(b, c // 8, n // 4)
+        g = TF.max_pool2(self.g(xg)).view(b, c // 2, n // 4)
         o = TF.attention_core(theta, phi, g).view(b, c // 2, h, w)          # g softmax(theta^T phi)^T
-        return TF.scale_add(self.gamma, self.o(o), x)
+        return TF.scale_add(self.gamma, self.o(o), xr)

@@ -8,6 +8,7 @@ registration order follow the reference so state_dicts interchange.
 """
 import functools
 
+import torch
 from torch import nn
 
 from ... import functional as TF
@@ -49,8 +50,12 @@ class ResidualGeneratorBlock(nn.Module):
             # the LOW resolution (a quarter of the traffic / FLOPs) and only their results are upsampled.
             # Where the low-resolution plane is large enough for the one-kernel form (TF.upconv3x3_pays), the first 3x3
             # conv is evaluated at the low resolution too: conv3x3(up2x(a)) = four 2x2-tap phase convs, 2.25x fewer FLOPs.
-            a = mods[0].forward_act(x, mods[1].negative_slope, replicate=4)
-            shortcut = TF.upsample_nearest2x(x if self.project_input is None else run_layers(self.project_input, x))
+            if x.requires_grad and torch.is_grad_enabled():
+                xa, xs = TF.fork(x, 2)           # two consumers: their gradients meet in one kernel instead of an autograd add
+            else:
+                xa = xs = x
+            a = mods[0].forward_act(xa, mods[1].negative_slope, replicate=4)
+            shortcut = TF.upsample_nearest2x(xs if self.project_input is None else run_layers(self.project_input, xs))
             conv = mods[2]
             if type(conv) is Conv2d and conv.kernel_size == (3, 3) and len(mods) > 3 and TF.upconv3x3_pays(a, conv.weight):
                 return run_layers(self.convs[3:], TF.upconv3x3(a, conv.weight, conv.bias), residual=shortcut)

@@ -239,7 +239,7 @@ class Emulator:
             _v(gx, B, C, HW).copy_(r)
         return 0
 
-    def bn_act_dbwd(self, v, vg, vb, gz, x, mean, invstd, gamma, beta, slope, a_gz, a_x, a_gamma, ws, B, C, HW):
+    def bn_act_dbwd(self, v, vg, vb, gz, x, mean, invstd, gamma, beta, slope, a_gz, a_x, a_gamma, ws, B, C, HW, accumulate=0):
         xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
         n = B * HW
         c = lambda t: t.view(1, C, 1)
@@ -257,7 +257,7 @@ class Emulator:
         _v(a_gz, B, C, HW).copy_(a_gyh * s)
         # adjoint of gamma: r * sum v P(gyh)
         A = S5 - S1 * S3 / n - S2 * S4 / n
-        a_gamma.copy_(r * A)
+        a_gamma.copy_(a_gamma + r * A if accumulate else r * A)
         # adjoint of x
         cg, cv = S4 / n, S2 / n
         q = -c(gamma * r) * (c(cg) * vv + c(cv) * gyh) + c(vg) * gyh
@@ -319,7 +319,7 @@ class Emulator:
         return 0
 
     def bn_sync_dbwd_finish(self, v, gz, x, mean, invstd, gamma, beta, slope, glob, count_global, world, a_gz, a_x, a_gamma,
-                            ws, B, C, HW):
+                            ws, B, C, HW, accumulate=0):
         xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
         n = float(count_global)
         c = lambda t: t.float().view(1, C, 1)
@@ -331,7 +331,7 @@ class Emulator:
         cg, cv = S4 / n, S2 / n
         qm = -g * r * (cg * S1 / n + cv * S3 / n)
         qx = -g * r * (cg * S2 / n + cv * S4 / n)
-        a_gamma.copy_((r * A / world).float())
+        a_gamma.copy_(a_gamma + (r * A / world).float() if accumulate else (r * A / world).float())
         Pv = vv - c(S1 / n) - xhat * c(S2 / n)
         _v(a_gz, B, C, HW).copy_(c(g * r) * Pv * s)
         q = -c(g * r) * (c(cg) * vv + c(cv) * gyh)
@@ -439,6 +439,15 @@ class Emulator:
     # ---------------------------------------------------------------- elementwise
     def add(self, a, b, out, n):
         out.copy_(a + b)
+        return 0
+
+    def add4(self, a, b, c, d, out, n):
+        r = a + b
+        if c is not None:
+            r = r + c
+        if d is not None:
+            r = r + d
+        out.copy_(r)
         return 0
 
     def mul(self, a, b, out, n):

@@ -302,7 +302,9 @@ def test_batchnorm_all_passes(K, shape):
         v = rnd(B, C, HW, seed=6)
         for vg, vb in ((rnd(C, seed=7), rnd(C, seed=8)), (None, None)):
             run_both(K, 'bn_act_dbwd', [v, vg, vb, gz, x, mean, invstd, gamma, beta, slope, torch.zeros(B, C, HW),
-                                        torch.zeros(B, C, HW), torch.zeros(C), ws, B, C, HW], [10, 11, 12], tol=5e-5)
+                                        torch.zeros(B, C, HW), torch.zeros(C), ws, B, C, HW, 0], [10, 11, 12], tol=5e-5)
+        run_both(K, 'bn_act_dbwd', [v, None, None, gz, x, mean, invstd, gamma, beta, slope, torch.zeros(B, C, HW),
+                                    torch.zeros(B, C, HW), rnd(C, seed=13), ws, B, C, HW, 1], [10, 11, 12], tol=5e-5)    # adj_gamma +=
 
 
 @pytest.mark.parametrize('shape', [(6, 4, 4), (8, 16, 16), (3, 64, 64), (5, 10, 6), (4, 128, 128), (3, 34, 20), (2, 256, 64), (5000, 16, 16)])

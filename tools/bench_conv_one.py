@@ -12,7 +12,9 @@ for spec in sys.argv[1:]:
     w = torch.randn(Cout, Cin, ks, ks, device='cuda'); bias = torch.randn(Cout, device='cuda')
     y = torch.empty(B, Cout, H, H, device='cuda'); gw = torch.empty_like(w); gb = torch.empty_like(bias)
     ws = torch.empty(K.conv2d_wgrad_workspace(B, Cin, Cout, H, H, ks) // 4 + 4, device='cuda')
+    gx = torch.empty_like(x)
     for _ in range(5):
         K.conv2d_fwd(x, w, bias, None, y, B, Cin, Cout, H, H, ks)
-        pass
+        K.conv2d_dgrad(gy, w, gx, B, Cin, Cout, H, H, ks)
+        K.conv2d_wgrad(x, gy, gw, gb, ws, ws.numel() * 4, B, Cin, Cout, H, H, ks, 0)
     torch.cuda.synchronize()

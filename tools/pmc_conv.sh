@@ -13,4 +13,4 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set -d $out/p$i --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/bench_conv_one.py $@ > $out/p$i.log 2>&1 || echo "pass $i failed"
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_conv_summary.py $out
+python3 $GRAFT_REPO_ROOT/tools/pmc_conv_summary.py $out > $out/summary.json; head -c 600 $out/summary.json

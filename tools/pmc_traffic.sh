@@ -3,7 +3,7 @@
 #   tools/pmc_traffic.sh <tag>     -> gpurun_out/traffic_<tag>/{fetch,write}/.../*counter_collection.csv
 # Two passes (FETCH_SIZE and WRITE_SIZE do not fit one), counters only (no API tracing), as the MI355X guide prescribes.
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/traffic_$tag
 mkdir -p $out

@@ -16,8 +16,12 @@ def load(d, counter):
             n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
             n = re.sub(r'^void ', '', n).split('(')[0]
             fam = re.sub(r'<.*', '', n)
-            if fam in ('conv_fwd_kernel', 'conv_dma_kernel'):
+            if fam == 'conv_fwd_kernel':
+                ks = re.search(r'conv_fwd_kernel<Geo<[^>]*>, (\d)', n)
+                fam += ' 1x1' if ks and ks.group(1) == '1' else ''
                 fam += ' (dgrad)' if re.search(r', true>$', n) else ' (fwd)'
+            elif fam == 'conv_dma_kernel':
+                fam += ' (dgrad)' if re.search(r', true, (true|false)>$', n) else ' (fwd)'
             agg[fam][0] += 1
             agg[fam][1] += float(r['Counter_Value'])
     return agg
@@ -38,7 +42,7 @@ here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sha = hashlib.sha256(open(os.path.join(here, 'tartangan_amd', 'csrc', 'conv.hip'), 'rb').read()).hexdigest()
 # the roofline family of bench.py: every kernel that produces activations / activation gradients of a 3x3 or stride-2 conv
 FAMILY = ('conv_fwd_kernel (fwd)', 'conv_fwd_kernel (dgrad)', 'conv_dma_kernel (fwd)', 'conv_dma_kernel (dgrad)', 'conv_upfwd_kernel',
-          'conv_upT_kernel', 'conv_upfwd_dma_kernel', 'conv_upT_dma_kernel', 'conv1x1_direct_kernel')
+          'conv_upT_kernel', 'conv_upfwd_dma_kernel', 'conv_upT_dma_kernel')          # (1x1 kernels: priced against HBM, listed apart)
 fl = sum(out[k]['launches_sampled'] for k in FAMILY if k in out)
 fb = sum(out[k]['launches_sampled'] * out[k]['hbm_bytes_per_launch'] for k in FAMILY if k in out)
 family = {'kernels': [k for k in FAMILY if k in out], 'launches_sampled': fl, 'hbm_bytes_per_launch': round(fb / max(fl, 1))}
