@@ -2009,6 +2009,96 @@ conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo,
   }
 }
 
+// ---- conv_wgrad_s2_kernel with LDS-DMA staging (single buffer, as conv_wgrad_dma_kernel): same split, accumulation
+// order and partial layout -> bit-identical partials.
+template <class G>
+__global__ void __launch_bounds__(CT_THREADS)
+conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__ lo, float* __restrict__ part, Shape s /*Cin = hi
+                         channels, Cout = lo channels, H x W = lo plane*/, int ntiles, int S) {
+  static_assert(G::NPIX == 256, "256-pixel tiles");
+  using P = DPatch2x<G>;
+  constexpr int CKW = S2_CKW, NT = S2_NT, CT = 16;
+  constexpr int PCH = CKW * P::CPC, GCH = CT * WGD_GYQ;
+  constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVG = (GCH + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCH * 4, BUF = PBUF + GCH * 4;
+  constexpr int RED = 4 * NT * 4 * 64;
+  __shared__ __attribute__((aligned(16))) float lds[BUF > RED ? BUF : RED];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, h = lane >> 4;
+  const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CKW;
+  const int split = blockIdx.x;
+  const int H2 = 2 * s.H, W2 = 2 * s.W;
+  const uint32_t HW = (uint32_t)(s.H * s.W), HW2 = (uint32_t)(H2 * W2);
+  int colbase[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) colbase[n] = n * P::CIS + (j >> 2) * P::PWS + (j & 3);
+  const int lane_b = P::pix(wave * 64) + 2 * h;
+  const int lane_a = j * WG_GYS + wave * 64 + h;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int cvalid = min(CKW, s.Cin - ci0);
+  for (int t = split; t < ntiles; t += S) {
+    const TileCoord tc = decode_tile<G>(t, s.H, s.W);
+    const char* xb = reinterpret_cast<const char*>(hi) + ((int64_t)tc.b0 * s.Cin + ci0) * HW2 * 4;
+    const int64_t xbytes = ((int64_t)(s.B - tc.b0) * s.Cin - ci0) * HW2 * 4;
+    const char* gb = reinterpret_cast<const char*>(lo) + ((int64_t)tc.b0 * s.Cout + co0) * HW * 4;
+    const int64_t gbytes = ((int64_t)(s.B - tc.b0) * s.Cout - co0) * HW * 4;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gb), 0, (int)gbytes, 0x00020000);
+    __syncthreads();                          // everybody is done reading the previous tile
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+      const int e = i * CT_THREADS + threadIdx.x;
+      const int ci = e / P::CPC, rem = e % P::CPC;
+      const int row = rem / P::QR, q = rem % P::QR;
+      const int img = row / P::PH, r = row % P::PH;
+      const int hh = 2 * tc.h0 - 1 + r, ww = 2 * tc.w0 - 4 + 4 * q;
+      const bool ok = (rem < P::RAW / 4) && (ci < cvalid) && (tc.b0 + img < s.B) && (hh >= 0) && (hh < H2) && (ww >= 0) && (ww < W2);
+      const uint32_t off = ok ? (__umul24(__umul24(img, s.Cin) + ci, HW2) + __umul24(hh, W2) + ww) << 2 : DMA_OOB;
+      if ((i + 1) * CT_THREADS <= PCH || e < PCH) dma16(rx, lds + (i * CT_THREADS + wave * 64) * 4, off);
+    }
+#pragma unroll
+    for (int i = 0; i < NVG; ++i) {
+      const int e = i * CT_THREADS + threadIdx.x;
+      const int co = e / WGD_GYQ, q = e % WGD_GYQ;
+      const int p = 4 * q;
+      const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
+      const int hh = tc.h0 + rem / G::TW, ww = tc.w0 + rem % G::TW;
+      const bool ok = (q < 64) && (co0 + co < s.Cout) && (tc.b0 + img < s.B) && (hh < s.H) && (ww < s.W);
+      const uint32_t off = ok ? (__umul24(__umul24(img, s.Cout) + co, HW) + __umul24(hh, s.W) + ww) << 2 : DMA_OOB;
+      if ((i + 1) * CT_THREADS <= GCH || e < GCH) dma16(rg, lds + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float* pl = lds;
+    const float* gl = lds + PBUF;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int pg = 4 * g;
+      const int goff = 2 * (pg / G::TW) * P::PWS + 2 * (pg % G::TW);
+      const float a = gl[lane_a + 4 * g];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[colbase[n] + lane_b + goff], acc[n], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* red = lds;
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave * NT + n) * 4 + r) * 64 + lane] = acc[n][r];
+  __syncthreads();
+  constexpr int PER_WAVE = NT * 4 * 64;
+  for (int e = threadIdx.x; e < PER_WAVE; e += CT_THREADS) {
+    const float v = (red[e] + red[PER_WAVE + e]) + (red[2 * PER_WAVE + e] + red[3 * PER_WAVE + e]);
+    const int l = e & 63, q = e >> 6;
+    const int r = q & 3, n = q >> 2;
+    const int co = co0 + (l >> 4) * 4 + r, ci = ci0 + n, tap = l & 15;
+    if (co < s.Cout && ci < s.Cin) part[(((int64_t)split * s.Cout + co) * s.Cin + ci) * 16 + tap] = v;
+  }
+}
+
 // Sum of the S partials of T (fixed order) and fold onto the 3x3 taps, in one kernel: a workgroup owns 4 (lo, hi)
 // channel pairs; thread = (pair, tap, S-slice), the 4 slices are combined through LDS, then 9 threads per pair fold.
 //   mode 0 (pooled conv, T[co][ci]):  gw[kh][kw] (+)= 0.25 sum_{dy,dx} T[dy+kh][dx+kw];
@@ -2512,7 +2602,11 @@ static int s2_wgrad(const float* hi, const float* lo, float* gw, float* ws, size
   Shape s{B, Chi, Clo, H, W};
   dim3 grid(S, lo_tiles, hi_chunks);
   const int vh = plane_vec_ok(hi, 2 * W), vl = plane_vec_ok(lo, W);
-  TG_S2_DISPATCH(g, conv_wgrad_s2_kernel, hi, lo, ws, s, tiles, S, vh, vl);
+  if (vh && vl && dma_knobs().enable && dma_knobs().wgrad && (int64_t)B * (Chi > Clo ? Chi : Clo) * H * W * 16 < (1ll << 31)) {
+    TG_S2_DISPATCH(g, conv_wgrad_s2_dma_kernel, hi, lo, ws, s, tiles, S);
+  } else {
+    TG_S2_DISPATCH(g, conv_wgrad_s2_kernel, hi, lo, ws, s, tiles, S, vh, vl);
+  }
   s2wgrad_reduce_fold_kernel<<<(Clo * Chi + 3) / 4, 256, 0, st>>>(ws, gw, S, Clo, Chi, Cout, Cin, mode, accumulate);
   return tg_launch_status();
 }
