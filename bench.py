@@ -46,7 +46,10 @@ def parse():
     p.add_argument('--no-kernel-timing', action='store_true')
     p.add_argument('--cpu-batch', type=int, default=None, help='batch of the CPU-baseline sample (default: --batch)')
     p.add_argument('--sync-bn', action='store_true', help='N>1: BatchNorm statistics of the GLOBAL batch (SyncBN)')
-    p.add_argument('--no-overlap', action='store_true', help='N>1: gradient all-reduces on the compute stream')
+    p.add_argument('--overlap', choices=['off', 'on', 'auto'], default='off',
+                   help='N>1: D-bucket all-reduce on a side stream under the generator forward.  off (default): serial schedule -- '
+                        'the collective is ~40 us of a ~6 ms step, and the side-stream path next to graph replay could only be '
+                        'rehearsed over gloo on this build\'s one-GPU boxes, where it stalls; auto: time both, keep the faster')
     p.add_argument('--backend', default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the DP code path)')
     p.add_argument('--share-gpu', action='store_true', help='rehearsal only: every rank uses cuda:0')
     return p.parse_args()
@@ -269,7 +272,7 @@ def main():
         from tartangan_amd.parallel import DataParallel
         if not a.eager:
             tr.enable_graphs()
-        dp = DataParallel(tr, sync_bn=a.sync_bn, overlap=False if a.no_overlap else None)
+        dp = DataParallel(tr, sync_bn=a.sync_bn, overlap=(a.overlap == 'on'))
     elif not a.eager:
         tr.enable_graphs()
     size = tr.g.max_size
@@ -281,6 +284,8 @@ def main():
     warm = max(a.warmup, 0 if a.eager else 2)  # graph mode: step 1 eager (records RNG plan), step 2 captures
     for _ in range(warm):
         logs = tr.train_batch(imgs)
+    if world > 1 and a.overlap == 'auto':       # (untimed) keep the side-stream all-reduce only if it is not slower here
+        dp.autotune_overlap(lambda: tr.train_batch(imgs))
 
     def fence():
         torch.cuda.synchronize()

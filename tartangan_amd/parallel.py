@@ -44,8 +44,10 @@ class DataParallel:
         self.trainer = trainer
         self.sync_bn = bool(sync_bn)
         on_device = str(trainer.device) != 'cpu'
-        self.overlap = on_device if overlap is None else bool(overlap)
-        self._side = torch.cuda.Stream() if (self.overlap and on_device) else None
+        # default: overlap with RCCL; gloo's device path (host staging with blocking synchronisation) stalls for seconds when
+        # a side-stream collective meets a replaying graph (measured: 23 ms -> 3 s per step with two ranks on one GPU)
+        self.overlap = (on_device and self.backend == 'nccl') if overlap is None else bool(overlap)
+        self._side = torch.cuda.Stream() if on_device else None
         self._pending = {}
         trainer.data_parallel = self
         feed = trainer.rng_feed
@@ -93,7 +95,7 @@ class DataParallel:
         them.  With a side stream the collective runs beside whatever the compute stream does in between."""
         if self.world == 1:
             return
-        if self._side is None:
+        if self._side is None or not self.overlap:
             self._reduce_now(flat_grads)
             return
         self._side.wait_stream(torch.cuda.current_stream())      # after the backward that produced the bucket
@@ -104,6 +106,29 @@ class DataParallel:
     def finish_all_reduce(self, key):
         if self._pending.pop(key, None) is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+
+    def autotune_overlap(self, step, steps=2):
+        """Time ``steps`` calls of ``step()`` with the side-stream schedule and with the serial one and keep the faster
+        (same decision on every rank: the timings are max-reduced).  Both schedules give identical numbers, so this is
+        purely a speed choice -- a guard against a collective library whose side-stream path misbehaves next to graph replay."""
+        import time
+        if self.world == 1 or self._side is None:
+            return self.overlap
+        took = []
+        for mode in (True, False):
+            self.overlap = mode
+            step()                                   # settle
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=self.trainer.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            took.append(float(t))
+        self.overlap = took[0] <= took[1] * 1.02
+        return self.overlap
 
     def shard(self, global_batch):
         """Rows of a globally-seeded batch that belong to this rank."""

@@ -46,7 +46,8 @@ def _worker(rank, world, port, kind, global_batch, mode, steps, out):
     tr = _build(kind, global_batch // world, seed=rank)
     if mode == 'graphs':
         tr.enable_graphs()
-    dp = DataParallel(tr, sync_bn=(mode == 'sync_bn'))
+    # (the side stream is explicit here: with gloo it is off by default -- slow next to graph replay, though correct)
+    dp = DataParallel(tr, sync_bn=(mode == 'sync_bn'), overlap=(mode == 'graphs'))
     imgs = dp.shard(synthetic_images(global_batch, 32, 4321)).cuda()
     torch.manual_seed(1234)
     logs = [tr.train_batch(imgs) for _ in range(steps)]
