@@ -22,12 +22,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(kind, batch, seed=0):
+def _build(kind, batch, seed=0, config='32', attention=(2,)):
     from tartangan_amd.models.pluggan import GAN_CONFIGS
     from tartangan_amd.trainers.cnn import CNNTrainer
     from tartangan_amd.trainers.iqn import IQNTrainer
     cls = {'cnn': CNNTrainer, 'iqn': IQNTrainer}[kind]
-    cfg = GAN_CONFIGS['32']._replace(attention=(2,))
+    cfg = GAN_CONFIGS[config]._replace(attention=tuple(attention))
     tr = cls(cls.default_args(config=cfg, batch_size=batch, device='cuda'))
     torch.manual_seed(seed)
     tr.build_models()
@@ -37,18 +37,18 @@ def _build(kind, batch, seed=0):
     return tr
 
 
-def _worker(rank, world, port, kind, global_batch, mode, steps, out):
+def _worker(rank, world, port, kind, global_batch, mode, steps, out, config='32', attention=(2,), size=32, img_seed=4321):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from tartangan_amd.parallel import DataParallel
-    tr = _build(kind, global_batch // world, seed=rank)
+    tr = _build(kind, global_batch // world, seed=rank, config=config, attention=attention)
     if mode == 'graphs':
         tr.enable_graphs()
     # (the side stream is explicit here: with gloo it is off by default -- slow next to graph replay, though correct)
     dp = DataParallel(tr, sync_bn=(mode == 'sync_bn'), overlap=(mode == 'graphs'))
-    imgs = dp.shard(synthetic_images(global_batch, 32, 4321)).cuda()
+    imgs = dp.shard(synthetic_images(global_batch, size, img_seed)).cuda()
     torch.manual_seed(1234)
     logs = [tr.train_batch(imgs) for _ in range(steps)]
     vals = torch.tensor([[l['g_loss'], l['d_loss'], l['gp']] for l in logs], dtype=torch.float64)
@@ -65,11 +65,11 @@ def _worker(rank, world, port, kind, global_batch, mode, steps, out):
     dist.destroy_process_group()
 
 
-def _run(kind, mode, steps, global_batch=8, world=2):
+def _run(kind, mode, steps, global_batch=8, world=2, **kw):
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, global_batch, mode, steps, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, global_batch, mode, steps, out), kwargs=kw) for r in range(world)]
     for p in procs:
         p.start()
     res = out.get(timeout=600)
@@ -104,3 +104,21 @@ def test_sync_bn_two_ranks_equal_single_process_full_batch(kind):
     assert res['rng_after'] == float(torch.rand(1))
     for got, name in zip(res['losses'][0], ('g_loss', 'd_loss', 'gp')):
         assert abs(got - want[name]) <= 1e-4 * max(abs(want[name]), 1e-6), (name, got, want[name])
+
+
+@pytest.mark.parametrize('case', ['c128a3_cnn_b64', 'c128a3_iqn_b64'])
+def test_sync_bn_two_ranks_reproduce_the_reference_fixture_at_the_global_batch(case):
+    """BASELINE.json configs 4 / 5 in miniature, at the benched model: the REFERENCE's own step at batch 64 (128:3,
+    fixtures written by its CNNTrainer / IQNTrainer) reproduced by two ranks of 32 images each with synchronised BatchNorm --
+    global z / tau streams sliced per rank, images sharded, gradients averaged.  1e-4 on the three losses, like one GPU."""
+    from conftest import load_golden
+    fx = load_golden(case)
+    assert fx['batch'] == 64 and fx['flags'] == {} if 'flags' in fx else True
+    # _build loads procedural weights with seeds 7/8/9 = the fixtures' weight_seed, +1, +2
+    assert fx['weight_seed'] == 7 and fx['rng_seed'] == 1234
+    res = _run(fx['trainer'], 'sync_bn', 1, global_batch=64, config=fx['config'], attention=fx['attention'],
+               size=fx['size'], img_seed=fx['img_seed'])
+    assert res['replicas_equal']
+    for got, name in zip(res['losses'][0], ('g_loss', 'd_loss', 'gp')):
+        want = fx['steps'][0][name]
+        assert abs(got - want) <= 1e-4 * max(abs(want), 1e-6), (case, name, got, want)

@@ -312,6 +312,22 @@ def test_foreign_training_loop_sees_stock_autograd_semantics():
         assert torch.allclose(p.grad, g, rtol=1e-4, atol=1e-6), (p.shape,)
 
 
+def test_hinge_losses_match_the_reference_formulas():
+    from tartangan_amd.models.losses import discriminator_hinge_loss, generator_hinge_loss
+    torch.manual_seed(4)
+    real, fake = torch.randn(9, 1, requires_grad=True), torch.randn(9, 1, requires_grad=True)
+    lr, lf = discriminator_hinge_loss(real, fake)
+    lg = generator_hinge_loss(fake)
+    want = (torch.relu(1. - real).mean(), torch.relu(1. + fake).mean(), -fake.mean())       # losses.py:7-14
+    for got, w in zip((lr, lf, lg), want):
+        assert torch.allclose(got, w.detach(), rtol=1e-6, atol=1e-7)
+    (lr + lf + lg).backward()
+    g_real, g_fake = real.grad.clone(), fake.grad.clone()
+    real.grad = fake.grad = None
+    (want[0] + want[1] + want[2]).backward()
+    assert torch.allclose(g_real, real.grad, atol=1e-7) and torch.allclose(g_fake, fake.grad, atol=1e-7)
+
+
 def test_product_has_no_cpu_fallback():
     backend._set_backend_for_testing(None)
     x = torch.zeros(1, 4, 4, 4)
