@@ -157,7 +157,9 @@ int tg_bn_act_fwd(const float* x, const float* mean, const float* invstd, const 
 int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const float* invstd,
                   const float* gamma, const float* beta, float slope, int training,
                   float* gx /*nullable*/, float* ggamma, float* gbeta, float* workspace,
-                  int B, int C, int HW, int accumulate /* ggamma, gbeta += */, void* stream);
+                  int B, int C, int HW, int accumulate /* ggamma, gbeta += */,
+                  const float* gx_add /*nullable: gx = ... + gx_add, a second gradient of x folded into the pass*/,
+                  void* stream);
 /* second backward of the training-mode map (gz, x, gamma) -> (gx, ggamma, gbeta)
  * (NativeBatchNormBackwardBackward0; R1 penalty path, models/losses.py:23-26).
  * v = adjoint of gx, vgamma/vbeta = adjoints of ggamma/gbeta (nullable = 0).   */
@@ -189,7 +191,8 @@ int tg_bn_sync_bwd_finish(const float* gz, const float* x, const float* mean, co
                           const float* gamma, const float* beta, float slope,
                           const double* local_sums /*[C][2]*/, const double* global_sums /*[C][2], all-reduced*/,
                           int64_t count_global, float* gx /*nullable*/, float* ggamma, float* gbeta,
-                          float* workspace, int B, int C, int HW, int accumulate, void* stream);
+                          float* workspace, int B, int C, int HW, int accumulate,
+                          const float* gx_add /*nullable*/, void* stream);
 int tg_bn_sync_dbwd_local(const float* v, const float* gz, const float* x, const float* mean,
                           const float* invstd, const float* gamma, const float* beta, float slope,
                           double* sums /*[C][5]*/, float* workspace, int B, int C, int HW, void* stream);

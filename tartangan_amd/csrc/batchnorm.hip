@@ -200,6 +200,7 @@ struct BwdBody {
   const float *gz, *x; float* gx;
   const float *mean, *invstd, *gamma, *beta, *coef;
   float slope; int training;
+  const float* add;          // nullable: a second gradient of x (the R1 penalty's second-order term) added in the same pass
   __device__ float elem(float g, float xv, float a, float b, float mu, float r, float k1, float k2) const {
     const float y = bn_y(xv, a, b);
     const float gyh = y >= 0.f ? g : g * slope;
@@ -213,11 +214,12 @@ struct BwdBody {
     float4 o;
     o.x = elem(g.x, v.x, a, b, mu, r, k1, k2); o.y = elem(g.y, v.y, a, b, mu, r, k1, k2);
     o.z = elem(g.z, v.z, a, b, mu, r, k1, k2); o.w = elem(g.w, v.w, a, b, mu, r, k1, k2);
+    if (add) { const float4 t = *reinterpret_cast<const float4*>(add + off); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
     *reinterpret_cast<float4*>(gx + off) = o;
   }
   __device__ void one(int c, int64_t off) const {
     const float r = invstd[c], mu = mean[c], a = gamma[c] * r, b = beta[c] - mu * a;
-    gx[off] = elem(gz[off], x[off], a, b, mu, r, coef[c * COEF + 0], coef[c * COEF + 1]);
+    gx[off] = elem(gz[off], x[off], a, b, mu, r, coef[c * COEF + 0], coef[c * COEF + 1]) + (add ? add[off] : 0.f);
   }
 };
 
@@ -229,6 +231,7 @@ struct BwdSumsBody {
   float *ggamma, *gbeta;
   float slope; int training, accumulate, B, HW, S;
   float a, b, mu, r, k1, k2;
+  const float* add;
   __device__ void begin(int c, bool lead) {
     const double n = (double)B * HW;
     const double sb = planes::gather(partial, c, S, 2, 0);
@@ -248,13 +251,14 @@ struct BwdSumsBody {
     const float gyh = y >= 0.f ? g : g * slope;
     return training ? a * (gyh - k1 - ((xv - mu) * r) * k2) : a * gyh;
   }
-  struct V { float4 g, v; };
+  struct V { float4 g, v, t; };
   __device__ V ld(int64_t off) const {
-    return V{*reinterpret_cast<const float4*>(gz + off), *reinterpret_cast<const float4*>(x + off)};
+    return V{*reinterpret_cast<const float4*>(gz + off), *reinterpret_cast<const float4*>(x + off),
+             add ? *reinterpret_cast<const float4*>(add + off) : make_float4(0.f, 0.f, 0.f, 0.f)};
   }
   __device__ void st(int c, int64_t off, const V& q) const {
     float4 o;
-    o.x = elem(q.g.x, q.v.x); o.y = elem(q.g.y, q.v.y); o.z = elem(q.g.z, q.v.z); o.w = elem(q.g.w, q.v.w);
+    o.x = elem(q.g.x, q.v.x) + q.t.x; o.y = elem(q.g.y, q.v.y) + q.t.y; o.z = elem(q.g.z, q.v.z) + q.t.z; o.w = elem(q.g.w, q.v.w) + q.t.w;
     *reinterpret_cast<float4*>(gx + off) = o;
   }
 };
@@ -433,7 +437,8 @@ __global__ void __launch_bounds__(SB) bn_small_bwd_kernel(const float* __restric
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
                                                           int training, float* __restrict__ gx, float* __restrict__ ggamma,
-                                                          float* __restrict__ gbeta, int B, int C, int HW, int accumulate) {
+                                                          float* __restrict__ gbeta, int B, int C, int HW, int accumulate,
+                                                          const float* __restrict__ add) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
   const SmallIdx ix(B, C, HW, c);
@@ -459,7 +464,7 @@ __global__ void __launch_bounds__(SB) bn_small_bwd_kernel(const float* __restric
   const float k1 = (float)(sb / n), k2 = (float)(sg / n);
 #pragma unroll
   for (int i = 0; i < SPER; ++i)
-    if (ix.ok[i]) gx[ix.off[i]] = training ? a * (gyh[i] - k1 - xh[i] * k2) : a * gyh[i];
+    if (ix.ok[i]) gx[ix.off[i]] = (training ? a * (gyh[i] - k1 - xh[i] * k2) : a * gyh[i]) + (add ? add[ix.off[i]] : 0.f);
 }
 
 __global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restrict__ v, const float* __restrict__ vgamma,
@@ -667,29 +672,30 @@ int tg_bn_act_fwd(const float* x, const float* mean, const float* invstd, const 
 
 int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, float slope, int training, float* gx, float* ggamma, float* gbeta, float* workspace,
-                  int B, int C, int HW, int accumulate, void* stream) {
+                  int B, int C, int HW, int accumulate, const float* gx_add, void* stream) {
   TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta);
   TG_CHECK_PTR(ggamma); TG_CHECK_PTR(gbeta); TG_CHECK_PTR(workspace);
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   hipStream_t st = tg_stream(stream);
   if (small_case(B, C, HW)) {
     bn_small_bwd_kernel<<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
-                                             accumulate);
+                                             accumulate, gx_add);
     return tg_launch_status();
   }
   Parts p = split_ws(workspace, B, C, HW);
   RedBwd red{gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
   planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz));
-  if (gx != nullptr && planes::big(HW) && tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx)) {
+  if (gx_add != nullptr && gx == nullptr) return TG_EINVAL;
+  if (gx != nullptr && planes::big(HW) && tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx) && (!gx_add || tg_aligned16(gx_add))) {
     BwdSumsBody body{gz, x, gx, p.partial, mean, invstd, gamma, beta, ggamma, gbeta, slope, training, accumulate,
-                     B, HW, planes::splits(B, C, HW), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                     B, HW, planes::splits(B, C, HW), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, gx_add};
     planes::launch_map_begin(body, B, C, HW, st);
     return tg_launch_status();
   }
   bwd_stage2<<<C, 64, 0, st>>>(p.partial, ggamma, gbeta, p.coef, B, C, HW, planes::splits(B, C, HW), accumulate);
   if (gx != nullptr) {
-    BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, training};
-    planes::launch_map(body, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx));
+    BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, training, gx_add};
+    planes::launch_map(body, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx) && (!gx_add || tg_aligned16(gx_add)));
   }
   return tg_launch_status();
 }
@@ -757,7 +763,7 @@ int tg_bn_sync_bwd_local(const float* gz, const float* x, const float* mean, con
 int tg_bn_sync_bwd_finish(const float* gz, const float* x, const float* mean, const float* invstd, const float* gamma,
                           const float* beta, float slope, const double* local_sums, const double* global_sums,
                           int64_t count_global, float* gx, float* ggamma, float* gbeta, float* workspace, int B, int C, int HW,
-                          int accumulate, void* stream) {
+                          int accumulate, const float* gx_add, void* stream) {
   TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta);
   TG_CHECK_PTR(local_sums); TG_CHECK_PTR(global_sums); TG_CHECK_PTR(ggamma); TG_CHECK_PTR(gbeta); TG_CHECK_PTR(workspace);
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
@@ -766,7 +772,7 @@ int tg_bn_sync_bwd_finish(const float* gz, const float* x, const float* mean, co
   Parts p = split_ws(workspace, B, C, HW);
   sync_bwd_finish<<<chan_grid(C), 64, 0, st>>>(local_sums, global_sums, (double)count_global, ggamma, gbeta, p.coef, C, accumulate);
   if (gx != nullptr) {
-    BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, 1};
+    BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, 1, gx_add};
     planes::launch_map(body, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx));
   }
   return tg_launch_status();

@@ -629,6 +629,19 @@ def _sums(like, C, k):
     return torch.empty(C * k, dtype=torch.float64, device=like.device)
 
 
+class _BNCell:
+    """Shared between one BatchNorm forward node and the first-order-backward node the R1 pass derives from it.  In the
+    final backward of the discriminator step the input x of a real-branch BatchNorm receives TWO gradients: the
+    second-order one (from ``_BNActBwd.backward``, reached first: the second-order sweep climbs the layers before the
+    ordinary backward descends them) and the first-order one (``_BNAct.backward``).  Inside ``grads_into_buckets()`` the
+    former is parked here and the latter adds it inside its own apply kernel (``gx_add``), instead of leaving a
+    full-tensor add to the autograd engine.  If the forward node ran first, nothing is parked (``consumed``)."""
+    __slots__ = ('pending', 'consumed')
+
+    def __init__(self):
+        self.pending, self.consumed = None, False
+
+
 class _BNAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, num_batches_tracked=None,
@@ -657,6 +670,7 @@ class _BNAct(Function):
             K().bn_act_fwd(x, mean, invstd, gamma, beta, float(slope), z, B, C, hw)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.training, ctx.slope, ctx.sync = bool(training), float(slope), sync
+        ctx.cell = _BNCell()
         return z
 
     @staticmethod
@@ -668,37 +682,41 @@ class _BNAct(Function):
             # plain backward: ggamma / gbeta accumulate straight into the flat bucket
             gz = gz.contiguous()
             gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-            _bn_bwd_into(gz, x, mean, invstd, gamma, beta, ctx.slope, ctx.training, gx, sink_g, sink_b, 1, ctx.sync)
+            cell = ctx.cell
+            extra, cell.pending, cell.consumed = cell.pending, None, True
+            if gx is None:
+                extra = None
+            _bn_bwd_into(gz, x, mean, invstd, gamma, beta, ctx.slope, ctx.training, gx, sink_g, sink_b, 1, ctx.sync, extra)
             return (gx, None, None) + nones
         gx, gg, gb = _BNActBwd.apply(gz, x, gamma, beta, mean, invstd, ctx.slope, ctx.training,
-                                     ctx.needs_input_grad[0], ctx.sync)
+                                     ctx.needs_input_grad[0], ctx.sync, ctx.cell)
         return (gx, gg, gb) + nones
 
 
-def _bn_bwd_into(gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, accumulate, sync):
+def _bn_bwd_into(gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, accumulate, sync, gx_add=None):
     B, C = x.shape[0], x.shape[1]
     hw = x[0, 0].numel()
     ws = _ws(x, K().bn_workspace(B, C, hw))
     if sync is None:
-        K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, slope, int(training), gx, gg, gb, ws, B, C, hw, accumulate)
+        K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, slope, int(training), gx, gg, gb, ws, B, C, hw, accumulate, gx_add)
         return
     local = _sums(x, C, 2)
     K().bn_sync_bwd_local(gz, x, mean, invstd, gamma, beta, slope, local, ws, B, C, hw)
     glob = sync.all_reduce(local.clone())
     K().bn_sync_bwd_finish(gz, x, mean, invstd, gamma, beta, slope, local, glob, sync.world * B * hw, gx, gg, gb, ws,
-                           B, C, hw, accumulate)
+                           B, C, hw, accumulate, gx_add)
 
 
 class _BNActBwd(Function):
     @staticmethod
-    def forward(ctx, gz, x, gamma, beta, mean, invstd, slope, training, need_gx=True, sync=None):
+    def forward(ctx, gz, x, gamma, beta, mean, invstd, slope, training, need_gx=True, sync=None, cell=None):
         gz = gz.contiguous()
         C = x.shape[1]
         gx = torch.empty_like(x) if need_gx else None
         gg, gb = x.new_empty(C), x.new_empty(C)
         _bn_bwd_into(gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, 0, sync)
         ctx.save_for_backward(gz, x, gamma, beta, mean, invstd)
-        ctx.slope, ctx.training, ctx.sync = slope, training, sync
+        ctx.slope, ctx.training, ctx.sync, ctx.cell = slope, training, sync, cell
         ctx.set_materialize_grads(False)        # the R1 pass never differentiates ggamma / gbeta: no zero fills for them
         return gx, gg, gb
 
@@ -718,7 +736,15 @@ class _BNActBwd(Function):
         if v is None:
             v = torch.zeros_like(x)
         v = v.contiguous()
-        nones = (None,) * 7
+        nones = (None,) * 8
+        cell = ctx.cell
+
+        def park(a_x):
+            # inside the trainers' backward: hand the second-order gradient of x to the forward node's backward (see _BNCell)
+            if _GradSinks.active and cell is not None and not cell.consumed and cell.pending is None and x.requires_grad:
+                cell.pending = a_x
+                return None
+            return a_x
         if ctx.sync is not None:
             if vg is not None or vb is not None:
                 raise NotImplementedError('synchronised BatchNorm: adjoints of ggamma / gbeta are not propagated '
@@ -728,10 +754,10 @@ class _BNActBwd(Function):
             ctx.sync.all_reduce(sums)
             K().bn_sync_dbwd_finish(v, gz, x, mean, invstd, gamma, beta, ctx.slope, sums, ctx.sync.world * B * hw,
                                     ctx.sync.world, a_gz, a_x, a_gamma, ws, B, C, hw, acc)
-            return (a_gz, a_x, a_gamma if sink is None else None) + nones
+            return (a_gz, park(a_x), a_gamma if sink is None else None) + nones
         K().bn_act_dbwd(v, None if vg is None else vg.contiguous(), None if vb is None else vb.contiguous(),
                         gz, x, mean, invstd, gamma, beta, ctx.slope, a_gz, a_x, a_gamma, ws, B, C, hw, acc)
-        return (a_gz, a_x, a_gamma if sink is None else None) + nones
+        return (a_gz, park(a_x), a_gamma if sink is None else None) + nones
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, slope=1.0,

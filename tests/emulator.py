@@ -222,7 +222,7 @@ class Emulator:
         _v(z, B, C, HW).copy_(y * s)
         return 0
 
-    def bn_act_bwd(self, gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, ws, B, C, HW, accumulate):
+    def bn_act_bwd(self, gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, ws, B, C, HW, accumulate, gx_add=None):
         xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
         gyh = _v(gz, B, C, HW) * s
         n = B * HW
@@ -236,6 +236,8 @@ class Emulator:
                 r = k * (gyh - sb.view(1, C, 1) / n - xhat * sg.view(1, C, 1) / n)
             else:
                 r = k * gyh
+            if gx_add is not None:
+                r = r + _v(gx_add, B, C, HW)
             _v(gx, B, C, HW).copy_(r)
         return 0
 
@@ -296,7 +298,7 @@ class Emulator:
         return 0
 
     def bn_sync_bwd_finish(self, gz, x, mean, invstd, gamma, beta, slope, local, glob, count_global, gx, gg, gb, ws, B, C, HW,
-                           accumulate):
+                           accumulate, gx_add=None):
         xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
         gyh = _v(gz, B, C, HW) * s
         lo, gl = local.view(C, 2), glob.view(C, 2)
@@ -306,7 +308,8 @@ class Emulator:
         if gx is not None:
             k1 = (gl[:, 0] / count_global).float().view(1, C, 1)
             k2 = (gl[:, 1] / count_global).float().view(1, C, 1)
-            _v(gx, B, C, HW).copy_((gamma * invstd).view(1, C, 1) * (gyh - k1 - xhat * k2))
+            r = (gamma * invstd).view(1, C, 1) * (gyh - k1 - xhat * k2)
+            _v(gx, B, C, HW).copy_(r if gx_add is None else r + _v(gx_add, B, C, HW))
         return 0
 
     def bn_sync_dbwd_local(self, v, gz, x, mean, invstd, gamma, beta, slope, sums, ws, B, C, HW):

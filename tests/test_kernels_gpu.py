@@ -296,9 +296,11 @@ def test_batchnorm_all_passes(K, shape):
         gz = rnd(B, C, HW, seed=5)
         for training in (1, 0):
             run_both(K, 'bn_act_bwd', [gz, x, mean, invstd, gamma, beta, slope, training, torch.zeros(B, C, HW),
-                                       torch.zeros(C), torch.zeros(C), ws, B, C, HW, 0], [8, 9, 10], tol=3e-5)
+                                       torch.zeros(C), torch.zeros(C), ws, B, C, HW, 0, None], [8, 9, 10], tol=3e-5)
         run_both(K, 'bn_act_bwd', [gz, x, mean, invstd, gamma, beta, slope, 1, None, rnd(C, seed=11), rnd(C, seed=12),
-                                   ws, B, C, HW, 1], [9, 10], tol=3e-5)
+                                   ws, B, C, HW, 1, None], [9, 10], tol=3e-5)
+        run_both(K, 'bn_act_bwd', [gz, x, mean, invstd, gamma, beta, slope, 1, torch.zeros(B, C, HW), torch.zeros(C), torch.zeros(C),
+                                   ws, B, C, HW, 0, rnd(B, C, HW, seed=14)], [8, 9, 10], tol=3e-5)       # gx = ... + gx_add
         v = rnd(B, C, HW, seed=6)
         for vg, vb in ((rnd(C, seed=7), rnd(C, seed=8)), (None, None)):
             run_both(K, 'bn_act_dbwd', [v, vg, vb, gz, x, mean, invstd, gamma, beta, slope, torch.zeros(B, C, HW),
