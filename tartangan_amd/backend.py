@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'tartangan_amd.h')
-LIBRARY = os.path.join(_HERE, 'csrc', 'libtartangan_amd.so')
+LIBRARY = os.environ.get('TG_LIBRARY') or os.path.join(_HERE, 'csrc', 'libtartangan_amd.so')   # TG_LIBRARY: a diagnostic build
 
 _CTYPES = {
     'const float*': ctypes.c_void_p, 'float*': ctypes.c_void_p,

@@ -581,9 +581,44 @@ template <int CT, int CK, bool DGRAD> struct DFilt {
 };
 constexpr uint32_t DMA_OOB = 0x80000000u;                        // >= any descriptor's num_records (tensors < 2 GiB)
 
+// LDS regions filled by LDS-DMA are padded to whole pieces (64 chunks = one wave instruction): every lane of an issuing
+// wave takes part -- lanes past the region's last chunk carry DMA_OOB and write zeros into the pad -- and whether a wave
+// issues piece i at all is a SCALAR condition on the wave index.  An LDS-DMA must never sit under a per-lane condition:
+// the compiler may merge such calls across the divergent branch (operands become per-lane phis), and the LDS base, which
+// is wave-uniform by contract and taken from the first active lane, then belongs to another piece for part of the lanes
+// (ROCm 7.2, conv_dma_kernel<G16, 32, 1, 8, fwd>: filter rows half loaded, the neighbouring buffer overwritten).
+constexpr int dma_pad(int chunks) { return (chunks + 63) & ~63; }
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_wave_base, uint32_t voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
+
+#ifdef TG_DIAG_STAMPS
+// Diagnostic build (make -C tartangan_amd/csrc diag -> libtartangan_amd_diag.so, loaded with TG_LIBRARY=...): every workgroup
+// of conv_dma_kernel leaves (shader cycles, 100 MHz ticks) of its main loop here; nothing else reads this buffer and no
+// output depends on it.  tools/clock_probe.py turns it into the clock the chip holds under the kernel.
+#define TG_DIAG_SLOTS 8192
+__device__ unsigned long long tg_diag_stamps[2 * TG_DIAG_SLOTS];
+extern "C" int tg_diag_read_stamps(unsigned long long* host, int n_slots) {
+  if (n_slots > TG_DIAG_SLOTS) return -1;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tg_diag_stamps), sizeof(unsigned long long) * 2 * n_slots);
+}
+__device__ unsigned long long tg_diag_phases[16 * TG_DIAG_SLOTS];
+extern "C" int tg_diag_read_phases(unsigned long long* host, int n_slots) {
+  if (n_slots > TG_DIAG_SLOTS) return -1;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tg_diag_phases), sizeof(unsigned long long) * 16 * n_slots);
+}
+__device__ unsigned long long tg_diag_life[16 * TG_DIAG_SLOTS];
+extern "C" int tg_diag_read_life(unsigned long long* host, int n_slots) {
+  if (n_slots > TG_DIAG_SLOTS) return -1;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tg_diag_life), sizeof(unsigned long long) * 16 * n_slots);
+}
+extern "C" int tg_diag_clear_stamps() {
+  static unsigned long long zeros[2 * TG_DIAG_SLOTS];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(tg_diag_stamps), zeros, sizeof(zeros));
+}
+#endif
 
 template <class G, int MF, int MT, int CK, bool DGRAD, bool DB = true>
 __global__ void __launch_bounds__(CT_THREADS)
@@ -597,15 +632,24 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
   constexpr int NT = Core::NT, KG = Core::KG, NG = CK / KG, NREG = Core::NREG;
   static_assert(!WK || NG % 4 == 0, "K-split needs a multiple of 4 k-groups per chunk");
   constexpr int PCH = CK * P::CPC, WCH = F::ROWS * F::QW;        // chunks per buffer: patch, filter
-  constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVW = (WCH + CT_THREADS - 1) / CT_THREADS;
-  constexpr int PBUF = PCH * 4, WBUF = WCH * 4;                  // floats; lanes past the last chunk of a region issue no DMA
+  constexpr int PCHP = dma_pad(PCH), WCHP = dma_pad(WCH);        // ... padded to whole wave pieces
+  constexpr int NVP = (PCHP + CT_THREADS - 1) / CT_THREADS, NVW = (WCHP + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCHP * 4, WBUF = WCHP * 4;                // floats
   constexpr int BUF = PBUF + WBUF;
   constexpr int REDF = WK ? 4 * MT * NT * NREG * 64 : 0;         // cross-wave reduction of the K-split partial sums
   constexpr int NBUF = DB ? 2 : 1;     // DB = false: one buffer, load -> barrier -> MFMA per chunk; the overlap then comes from the
                                        // other workgroups of the CU (half the LDS: more of them, and exact occupancy rounds)
   __shared__ __attribute__((aligned(16))) float lds[(NBUF * BUF > REDF) ? NBUF * BUF : REDF];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef TG_DIAG_STAMPS
+  const uint64_t st_begin = __builtin_amdgcn_s_memtime();
+#endif
+  // Wave priority: the short serial sections (setup, DMA issue, barrier, epilogue) run ahead of the other waves' MFMA streams.
+  // A young wave otherwise gets the vector issue port only when no older wave has an MFMA waiting (stamps: 8 k cycles of
+  // setup for ~200 instructions on the 128^2 layers, 4 k with this); +1.5 % over the layer set, up to +4.5 % per layer.
+  const bool prio = (xcd_swizzle & 32) != 0;
+  if (prio) __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int j = lane % MF, h = lane / MF;
   int bid = blockIdx.x;
   if (xcd_swizzle & 1) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);     // an XCD (block id mod 8) works on neighbouring tiles
@@ -648,30 +692,37 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
   int64_t wbytes = (int64_t)s.Cin * s.Cout * 9 * 4 - (wb - reinterpret_cast<const char*>(w));
   const int64_t wstep = DGRAD ? (int64_t)CK * s.Cout * 9 * 4 : (int64_t)CK * 9 * 4;
 
-  auto issue = [&](int c0, float* buf) {
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)xbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wb), 0, (int)wbytes, 0x00020000);
-    const int cvalid = s.Cin - c0;                              // channels of this chunk that exist (>= CK: all)
-#pragma unroll
-    for (int i = 0; i < NVP; ++i) {
+  // one 1-KiB piece (a wave instruction) of a chunk: pieces 0 .. NVP-1 the patch, NVP .. NVP+NVW-1 the filter slice
+  constexpr int NPIECE = NVP + NVW;
+  auto issue_piece = [&](int i, float* buf, const __amdgpu_buffer_rsrc_t rx, const __amdgpu_buffer_rsrc_t rw, int cvalid) {
+    if (i < NVP) {
       uint32_t off = poff[i];
       if (cvalid < CK) off = ((i * CT_THREADS + (int)threadIdx.x) / P::CPC < cvalid) ? off : DMA_OOB;
-      if ((i + 1) * CT_THREADS <= PCH || i * CT_THREADS + (int)threadIdx.x < PCH)
+      if ((i + 1) * CT_THREADS <= PCHP || i * CT_THREADS + wave * 64 < PCHP)      // (scalar)
         dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
-    }
-#pragma unroll
-    for (int i = 0; i < NVW; ++i) {
+    } else {
+      i -= NVP;
       uint32_t off = woff[i];
       if (cvalid < CK) {
         const int e = i * CT_THREADS + (int)threadIdx.x;
         const bool in = DGRAD ? (e / F::QW < cvalid) : (4 * (e % F::QW) < cvalid * 9);
         off = in ? off : DMA_OOB;
       }
-      if ((i + 1) * CT_THREADS <= WCH || i * CT_THREADS + (int)threadIdx.x < WCH)
+      if ((i + 1) * CT_THREADS <= WCHP || i * CT_THREADS + wave * 64 < WCHP)
         dma16(rw, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
     }
+  };
+  auto advance = [&]() {
     xb += xstep; xbytes -= xstep;
     wb += wstep; wbytes -= wstep;
+  };
+  auto issue = [&](int c0, float* buf) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wb), 0, (int)wbytes, 0x00020000);
+    const int cvalid = s.Cin - c0;                              // channels of this chunk that exist (>= CK: all)
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) issue_piece(i, buf, rx, rw, cvalid);
+    advance();
   };
 
   // ---- fragment addresses
@@ -684,21 +735,45 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
   typename Core::acc_t acc[MT][NT];
   Core::zero(acc);
 
+#ifdef TG_DIAG_STAMPS
+  asm volatile("" :: "v"(poff[0]), "v"(woff[0]), "v"(lane_b[0]), "v"(lane_a));
+  const uint64_t st_setup = __builtin_amdgcn_s_memtime();
+#endif
   if (DB) issue(0, lds);
   int buf = 0;
+#ifdef TG_DIAG_STAMPS
+  const uint64_t st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  uint64_t st_wait = 0, st_bar = 0, st_issue = 0, st_mfma = 0, st_prev = 0, st_last = 0;
+#endif
   for (int c0 = 0; c0 < s.Cin; c0 += CK) {
     if constexpr (!DB) {
       __syncthreads();                                         // everybody is done reading the previous chunk
       issue(c0, lds);
     }
+#ifdef TG_DIAG_STAMPS
+    const uint64_t ph0 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMAs of chunk c0 have landed ...
+#ifdef TG_DIAG_STAMPS
+    const uint64_t ph1 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();                                           // ... and everybody's; everybody is done reading the other buffer
+#ifdef TG_DIAG_STAMPS
+    const uint64_t ph2 = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (DB) {
       if (c0 + CK < s.Cin) issue(c0 + CK, lds + (buf ^ 1) * BUF);
     }
+#ifdef TG_DIAG_STAMPS
+    const uint64_t ph3 = __builtin_amdgcn_s_memtime();
+    st_wait += ph1 - ph0; st_bar += ph2 - ph1; st_issue += ph3 - ph2; st_last = ph3;
+    if (c0 > 0) st_mfma += ph0 - st_prev;
+    st_prev = ph3;
+#endif
     const float* pl = lds + buf * BUF;
     const float* wl = pl + PBUF;
     if (xcd_swizzle & 4) { buf ^= 1; continue; }               // diagnostic build only: no MFMAs
+    if (prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int gi = 0; gi < NG / (WK ? 4 : 1); ++gi) {
       const int g = gi * (WK ? 4 : 1);                           // (+ g0, in the lane bases)
@@ -722,8 +797,21 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
           }
       }
     }
+    if (prio) __builtin_amdgcn_s_setprio(3);
     if (DB) buf ^= 1;
   }
+#ifdef TG_DIAG_STAMPS
+  {   // diagnostic build only (make diag): shader clock held over the main loop = d(memtime) / d(memrealtime) x 100 MHz
+    const uint64_t st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+    const int slot = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && slot < TG_DIAG_SLOTS) { tg_diag_stamps[2 * slot] = st_c1 - st_c0; tg_diag_stamps[2 * slot + 1] = st_r1 - st_r0; }
+    st_mfma += st_c1 - st_last;                                 // per wave: cycles in (vmcnt wait, barrier, DMA issue, MFMA phase)
+    if (lane == 0 && slot < TG_DIAG_SLOTS) {
+      unsigned long long* ph = tg_diag_phases + (slot * 4 + wave) * 4;
+      ph[0] = st_wait; ph[1] = st_bar; ph[2] = st_issue; ph[3] = st_mfma;
+    }
+  }
+#endif
   if constexpr (WK) {
     // sum the four waves' partial accumulators through LDS (fixed order), as conv_fwd_kernel does
     __syncthreads();
@@ -748,6 +836,18 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
   }
   if ((xcd_swizzle & 2) && acc[0][0][0] != 12345.678f) return;   // diagnostic build only: no epilogue
   Core::epilogue(acc, bias, residual, y, s, tc, co0, pix0, j, h, wave);
+#ifdef TG_DIAG_STAMPS
+  {   // workgroup life: entry -> loop, loop -> stores issued, ... -> stores acknowledged
+    const uint64_t e0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint64_t e1 = __builtin_amdgcn_s_memtime();
+    const int slot = blockIdx.y * gridDim.x + blockIdx.x;
+    if (lane == 0 && slot < TG_DIAG_SLOTS) {
+      unsigned long long* ph = tg_diag_life + (slot * 4 + wave) * 4;
+      ph[0] = st_c0 - st_begin; ph[1] = e0 - st_c0; ph[2] = e1 - e0; ph[3] = st_setup - st_begin;
+    }
+  }
+#endif
 }
 
 // =========================================================================== 1x1, few channels: direct kernel
@@ -1032,13 +1132,14 @@ conv_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
   using P = DPatch<G>;
   constexpr int KK = 9, CT = 16 * MTW, NCOL = CKW * KK, NT = (NCOL + 15) / 16;
   constexpr int PCH = CKW * P::CPC, GCH = CT * WGD_GYQ;
-  constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVG = (GCH + CT_THREADS - 1) / CT_THREADS;
-  constexpr int PBUF = PCH * 4, BUF = PBUF + GCH * 4;
+  constexpr int PCHP = dma_pad(PCH), GCHP = dma_pad(GCH);        // regions of whole wave pieces (see dma_pad)
+  constexpr int NVP = (PCHP + CT_THREADS - 1) / CT_THREADS, NVG = (GCHP + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCHP * 4, BUF = PBUF + GCHP * 4;
   constexpr int RED = 4 * MTW * NT * 4 * 64 + 4 * CT;
   constexpr int LDSF = ((DB ? 2 : 1) * BUF > RED) ? (DB ? 2 : 1) * BUF : RED;
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int j = lane & 15, h = lane >> 4;
   const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CKW;
   const int split = blockIdx.x;
@@ -1082,7 +1183,7 @@ conv_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
       const int hh = tc.h0 + r - 1, ww = tc.w0 - 4 + 4 * q;
       const bool ok = (rem < P::RAW / 4) && (ci < cvalid) && (tc.b0 + img < s.B) && (hh >= 0) && (hh < s.H) && (ww >= 0) && (ww < s.W);
       const uint32_t off = ok ? (__umul24(__umul24(img, s.Cin) + ci, HW) + __umul24(hh, s.W) + ww) << 2 : DMA_OOB;
-      if ((i + 1) * CT_THREADS <= PCH || e < PCH) dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
+      if ((i + 1) * CT_THREADS <= PCHP || i * CT_THREADS + wave * 64 < PCHP) dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
     }
 #pragma unroll
     for (int i = 0; i < NVG; ++i) {
@@ -1091,9 +1192,9 @@ conv_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
       const int p = 4 * q;
       const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
       const int hh = tc.h0 + rem / G::TW, ww = tc.w0 + rem % G::TW;
-      const bool ok = (q < 64) && (co0 + co < s.Cout) && (tc.b0 + img < s.B) && (hh < s.H) && (ww < s.W);
+      const bool ok = (e < GCH) && (q < 64) && (co0 + co < s.Cout) && (tc.b0 + img < s.B) && (hh < s.H) && (ww < s.W);
       const uint32_t off = ok ? (__umul24(__umul24(img, s.Cout) + co, HW) + __umul24(hh, s.W) + ww) << 2 : DMA_OOB;
-      if ((i + 1) * CT_THREADS <= GCH || e < GCH) dma16(rg, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
+      if ((i + 1) * CT_THREADS <= GCHP || i * CT_THREADS + wave * 64 < GCHP) dma16(rg, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
     }
   };
   auto compute = [&](const float* buf) {
@@ -1629,11 +1730,12 @@ conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t,
   using Core = FwdCore<G, 3, 16, 1, WK>;
   constexpr int RS = CK * KK + 4, QW = RS / 4;
   constexpr int PCH = CK * P::CPC, WCH = CT * QW;
-  constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVW = (WCH + CT_THREADS - 1) / CT_THREADS;
-  constexpr int PBUF = PCH * 4, BUF = PBUF + WCH * 4;
+  constexpr int PCHP = dma_pad(PCH), WCHP = dma_pad(WCH);        // regions of whole wave pieces (see dma_pad)
+  constexpr int NVP = (PCHP + CT_THREADS - 1) / CT_THREADS, NVW = (WCHP + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCHP * 4, BUF = PBUF + WCHP * 4;
   constexpr int REDF = WK ? 4 * NT * 4 * 64 : 0, NBUF = DB ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[(NBUF * BUF > REDF) ? NBUF * BUF : REDF];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int j = lane & 15, h = lane >> 4;
   int bid = blockIdx.x;
   if (xcd_swizzle) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
@@ -1676,13 +1778,13 @@ conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t,
     for (int i = 0; i < NVP; ++i) {
       uint32_t off = poff[i];
       if (cvalid < CK) off = ((i * CT_THREADS + (int)threadIdx.x) / P::CPC < cvalid) ? off : DMA_OOB;
-      if ((i + 1) * CT_THREADS <= PCH || i * CT_THREADS + (int)threadIdx.x < PCH) dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
+      if ((i + 1) * CT_THREADS <= PCHP || i * CT_THREADS + wave * 64 < PCHP) dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
     }
 #pragma unroll
     for (int i = 0; i < NVW; ++i) {
       uint32_t off = woff[i];
       if (cvalid < CK) off = (4 * ((i * CT_THREADS + (int)threadIdx.x) % QW) < cvalid * KK) ? off : DMA_OOB;
-      if ((i + 1) * CT_THREADS <= WCH || i * CT_THREADS + (int)threadIdx.x < WCH) dma16(rw, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
+      if ((i + 1) * CT_THREADS <= WCHP || i * CT_THREADS + wave * 64 < WCHP) dma16(rw, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
     }
     xb += xstep; xbytes -= xstep;
     wb += wstep; wbytes -= wstep;
@@ -1745,11 +1847,12 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
   using P = DPatch<G>;
   constexpr int RS = CK * KK + 4, QW = RS / 4, WSZ = CT * RS;        // one phase's filter image
   constexpr int PCH = CK * P::CPC, WCH = 4 * CT * QW;
-  constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVW = (WCH + CT_THREADS - 1) / CT_THREADS;
-  constexpr int PBUF = PCH * 4, BUF = PBUF + WCH * 4;
+  constexpr int PCHP = dma_pad(PCH), WCHP = dma_pad(WCH);        // regions of whole wave pieces (see dma_pad)
+  constexpr int NVP = (PCHP + CT_THREADS - 1) / CT_THREADS, NVW = (WCHP + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCHP * 4, BUF = PBUF + WCHP * 4;
   constexpr int REDF = WK ? 4 * 2 * NT * 4 * 64 : 0, NBUF = DB ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[(NBUF * BUF > REDF) ? NBUF * BUF : REDF];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int j = lane & 15, h = lane >> 4;
   int bid = blockIdx.x;
   if (xcd_swizzle) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
@@ -1793,13 +1896,13 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
     for (int i = 0; i < NVP; ++i) {
       uint32_t off = poff[i];
       if (cvalid < CK) off = ((i * CT_THREADS + (int)threadIdx.x) / P::CPC < cvalid) ? off : DMA_OOB;
-      if ((i + 1) * CT_THREADS <= PCH || i * CT_THREADS + (int)threadIdx.x < PCH) dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
+      if ((i + 1) * CT_THREADS <= PCHP || i * CT_THREADS + wave * 64 < PCHP) dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, off);
     }
 #pragma unroll
     for (int i = 0; i < NVW; ++i) {
       uint32_t off = woff[i];
       if (cvalid < CK) off = (4 * ((i * CT_THREADS + (int)threadIdx.x) % QW) < cvalid * KK) ? off : DMA_OOB;
-      if ((i + 1) * CT_THREADS <= WCH || i * CT_THREADS + (int)threadIdx.x < WCH) dma16(rw, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
+      if ((i + 1) * CT_THREADS <= WCHP || i * CT_THREADS + wave * 64 < WCHP) dma16(rw, buf + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
     }
     xb += xstep; xbytes -= xstep;
     wb += wstep; wbytes -= wstep;
@@ -2019,11 +2122,12 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
   using P = DPatch2x<G>;
   constexpr int CKW = S2_CKW, NT = S2_NT, CT = 16;
   constexpr int PCH = CKW * P::CPC, GCH = CT * WGD_GYQ;
-  constexpr int NVP = (PCH + CT_THREADS - 1) / CT_THREADS, NVG = (GCH + CT_THREADS - 1) / CT_THREADS;
-  constexpr int PBUF = PCH * 4, BUF = PBUF + GCH * 4;
+  constexpr int PCHP = dma_pad(PCH), GCHP = dma_pad(GCH);        // regions of whole wave pieces (see dma_pad)
+  constexpr int NVP = (PCHP + CT_THREADS - 1) / CT_THREADS, NVG = (GCHP + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCHP * 4, BUF = PBUF + GCHP * 4;
   constexpr int RED = 4 * NT * 4 * 64;
   __shared__ __attribute__((aligned(16))) float lds[BUF > RED ? BUF : RED];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int j = lane & 15, h = lane >> 4;
   const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CKW;
   const int split = blockIdx.x;
@@ -2056,7 +2160,7 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
       const int hh = 2 * tc.h0 - 1 + r, ww = 2 * tc.w0 - 4 + 4 * q;
       const bool ok = (rem < P::RAW / 4) && (ci < cvalid) && (tc.b0 + img < s.B) && (hh >= 0) && (hh < H2) && (ww >= 0) && (ww < W2);
       const uint32_t off = ok ? (__umul24(__umul24(img, s.Cin) + ci, HW2) + __umul24(hh, W2) + ww) << 2 : DMA_OOB;
-      if ((i + 1) * CT_THREADS <= PCH || e < PCH) dma16(rx, lds + (i * CT_THREADS + wave * 64) * 4, off);
+      if ((i + 1) * CT_THREADS <= PCHP || i * CT_THREADS + wave * 64 < PCHP) dma16(rx, lds + (i * CT_THREADS + wave * 64) * 4, off);
     }
 #pragma unroll
     for (int i = 0; i < NVG; ++i) {
@@ -2065,9 +2169,9 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
       const int p = 4 * q;
       const int img = p / (G::TH * G::TW), rem = p % (G::TH * G::TW);
       const int hh = tc.h0 + rem / G::TW, ww = tc.w0 + rem % G::TW;
-      const bool ok = (q < 64) && (co0 + co < s.Cout) && (tc.b0 + img < s.B) && (hh < s.H) && (ww < s.W);
+      const bool ok = (e < GCH) && (q < 64) && (co0 + co < s.Cout) && (tc.b0 + img < s.B) && (hh < s.H) && (ww < s.W);
       const uint32_t off = ok ? (__umul24(__umul24(img, s.Cout) + co, HW) + __umul24(hh, s.W) + ww) << 2 : DMA_OOB;
-      if ((i + 1) * CT_THREADS <= GCH || e < GCH) dma16(rg, lds + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
+      if ((i + 1) * CT_THREADS <= GCHP || i * CT_THREADS + wave * 64 < GCHP) dma16(rg, lds + PBUF + (i * CT_THREADS + wave * 64) * 4, off);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -2310,10 +2414,11 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, const floa
 
 // ---- LDS-DMA kernel dispatch.  Tuning knobs are read once from the environment (development only; the defaults are the
 // measured best): TG_CONV_DMA=0 disables the kernel, TG_DMA_TILE=256|512 and TG_DMA_CK=4|8 force a tile / chunk size.
-struct DmaKnobs { int enable, tile, ck, ksplit, wgrad, wgrad_db, s2, db, diag; };
+struct DmaKnobs { int enable, tile, ck, ksplit, wgrad, wgrad_db, s2, db, diag, prio; };
 static const DmaKnobs& dma_knobs() {
   static const DmaKnobs k = [] {
-    DmaKnobs d{1, 0, 0, 1, 1, 0, 1, 1, 0};
+    DmaKnobs d{1, 0, 0, 1, 1, 0, 1, 1, 0, 1};
+    if (const char* e = getenv("TG_DMA_PRIO")) d.prio = atoi(e);
     if (const char* e = getenv("TG_DMA_DIAG")) d.diag = atoi(e) & 6;
     if (const char* e = getenv("TG_DMA_DB")) d.db = atoi(e);
     if (const char* e = getenv("TG_DMA_S2")) d.s2 = atoi(e);
@@ -2344,7 +2449,7 @@ static bool s2_single_buffer() { return dma_knobs().db == 0; }
 template <class G, int CK, bool DGRAD>
 static bool launch_dma_geo(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
   const int64_t tiles = num_tiles<G>(s.B, s.H, s.W);
-  const int swz = ((tiles % 8 == 0) ? 1 : 0) | dma_knobs().diag;
+  const int swz = ((tiles % 8 == 0) ? 1 : 0) | dma_knobs().diag | (dma_knobs().prio ? 32 : 0);
   const bool use32 = (s.Cout % 32 == 0) || s.Cout > 48;
   // output-channel tile: as wide as the grid allows (one workgroup per CU at the very least)
   const bool sb = dma_knobs().db == 0;
@@ -2365,7 +2470,7 @@ static bool launch_dma_geo(const float* x, const float* w, const float* bias, co
 template <class G, bool DGRAD>
 static bool launch_dma_ksplit(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
   const int64_t tiles = num_tiles<G>(s.B, s.H, s.W);
-  const int swz = (tiles % 8 == 0) ? 1 : 0;
+  const int swz = ((tiles % 8 == 0) ? 1 : 0) | (dma_knobs().prio ? 32 : 0);
   if (s.Cout % 32 == 0 || s.Cout > 48)
     conv_dma_kernel<G, 32, 1, 16, DGRAD><<<dim3(tiles, (s.Cout + 31) / 32), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
   else
@@ -2452,7 +2557,7 @@ int launch_wgrad_geo(const float* x, const float* gy, float* part, float* bias_p
     const DmaKnobs& k = dma_knobs();
     const bool small = (int64_t)s.B * (s.Cin > s.Cout ? s.Cin : s.Cout) * s.H * s.W * 4 < (1ll << 31);
     constexpr int CKW = WgCfg<3>::CKW;
-    constexpr int buf1 = (CKW * DPatch<G>::CPC + 16 * WGD_GYQ) * 16, buf2 = (CKW * DPatch<G>::CPC + 32 * WGD_GYQ) * 16;   // bytes, MTW 1 / 2
+    constexpr int buf1 = (dma_pad(CKW * DPatch<G>::CPC) + dma_pad(16 * WGD_GYQ)) * 16, buf2 = (dma_pad(CKW * DPatch<G>::CPC) + dma_pad(32 * WGD_GYQ)) * 16;   // bytes, MTW 1 / 2
     if (k.enable && k.wgrad && vx && vg && small) {
       // (two buffers -- the next tile in flight under this tile's MFMAs -- measured slower at every shape of the 128 px step:
       // they halve the workgroups per CU; kept behind TG_DMA_WGRAD_DB=1 for wider layers)

@@ -72,6 +72,79 @@ def test_conv_fwd(K, shape):
     run_both(K, 'conv2d_fwd', [x, w, b, rnd(B, Cout, H, W, seed=7), torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, ks], [4], tol=2e-5)
 
 
+# The step's own 3x3 layers AT THE BENCHED BATCH (64): the launch heuristics pick other tile / chunk / K-split variants here
+# than on the small cases above (e.g. conv_dma_kernel<G16, 32, 1, 8> needs >= 64 images of 16x16).
+STEP_CONV_SHAPES = [(64, 128, 128, 16, 16, 3), (64, 64, 128, 16, 16, 3), (64, 128, 64, 16, 16, 3), (64, 128, 64, 32, 32, 3), (64, 64, 64, 32, 32, 3),
+                    (64, 32, 64, 32, 32, 3), (64, 32, 32, 64, 64, 3), (64, 64, 32, 64, 64, 3), (64, 16, 16, 128, 128, 3), (64, 32, 16, 128, 128, 3),
+                    (64, 4, 16, 128, 128, 3), (64, 128, 128, 8, 8, 3), (64, 128, 128, 4, 4, 3), (64, 256, 256, 8, 8, 3)]
+
+
+def poison_lds(K):
+    """Leave NaNs in the LDS of every CU: LDS is not cleared between kernels, so a kernel that reads a cell it did not write
+    (a lane that skipped its LDS-DMA, a pad it assumed zero) computes NaN afterwards instead of passing by luck."""
+    nan = torch.full((64, 32, 64, 64), float('nan'), device='cuda')
+    w = torch.full((32, 32, 3, 3), float('nan'), device='cuda')
+    y = torch.empty(64, 32, 64, 64, device='cuda')
+    K.conv2d_fwd(nan, w, None, None, y, 64, 32, 32, 64, 64, 3)
+    gw = torch.empty_like(w)
+    ws = torch.empty(K.conv2d_wgrad_workspace(64, 32, 32, 64, 64, 3) // 4 + 4, device='cuda')
+    K.conv2d_wgrad(nan, nan, gw, None, ws, ws.numel() * 4, 64, 32, 32, 64, 64, 3, 0)
+    nan8 = torch.full((64, 128, 8, 8), float('nan'), device='cuda')
+    w8 = torch.full((128, 128, 3, 3), float('nan'), device='cuda')
+    K.conv2d_fwd(nan8, w8, None, None, torch.empty_like(nan8), 64, 128, 128, 8, 8, 3)
+    hi = torch.full((64, 32, 64, 64), float('nan'), device='cuda'); lo = torch.empty(64, 32, 32, 32, device='cuda')
+    K.poolconv3x3_fwd(hi, torch.full((32, 32, 4, 4), float('nan'), device='cuda'), None, None, lo, 64, 32, 32, 32, 32)
+    K.upconv3x3_fwd(lo.fill_(float('nan')), torch.full((4, 32, 32, 2, 2), float('nan'), device='cuda'), None, None, hi, 64, 32, 32, 32, 32)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('shape', STEP_CONV_SHAPES)
+def test_conv_step_shapes_full_batch_after_lds_poison(K, shape):
+    B, Cin, Cout, H, W, ks = shape
+    x, w, b = rnd(B, Cin, H, W), rnd(Cout, Cin, ks, ks, scale=0.2), rnd(Cout)
+    gy = rnd(B, Cout, H, W, seed=3)
+    poison_lds(K)
+    run_both(K, 'conv2d_fwd', [x, w, b, None, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W, ks], [4], tol=2e-5)
+    poison_lds(K)
+    run_both(K, 'conv2d_dgrad', [gy, w, torch.zeros(B, Cin, H, W), B, Cin, Cout, H, W, ks], [2], tol=2e-5)
+    ws = torch.zeros(K.conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks) // 4 + 4)
+    poison_lds(K)
+    run_both(K, 'conv2d_wgrad', [x, gy, torch.zeros(Cout, Cin, ks, ks), torch.zeros(Cout), ws, ws.numel() * 4, B, Cin, Cout, H, W, ks, 0],
+             [2, 3], tol=5e-5, scratch=[4])
+
+
+STEP_S2_SHAPES = [(64, 128, 128, 8, 8), (64, 128, 64, 16, 16), (64, 64, 32, 32, 32), (64, 32, 16, 64, 64)]
+
+
+@pytest.mark.parametrize('shape', STEP_S2_SHAPES)
+def test_stride2_step_shapes_full_batch_after_lds_poison(K, shape):
+    B, Cin, Cout, H, W = shape                     # H x W: the low-resolution plane
+    a, w, b = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, scale=0.2), rnd(Cout)
+    wp, w4t = torch.zeros(4, Cout, Cin, 2, 2), torch.zeros(Cin, Cout, 4, 4)
+    E.upconv3x3_weights(w, wp, Cout, Cin)
+    E.upconv3x3_weights_t(w, w4t, Cout, Cin)
+    gyh = rnd(B, Cout, 2 * H, 2 * W, seed=3)
+    poison_lds(K)
+    run_both(K, 'upconv3x3_fwd', [a, wp, b, None, torch.zeros(B, Cout, 2 * H, 2 * W), B, Cin, Cout, H, W], [4], tol=3e-5)
+    if K.upconv3x3_dgrad_supported(B, Cin, Cout, H, W):        # (4x4 source planes take the composed path in the layer)
+        poison_lds(K)
+        run_both(K, 'upconv3x3_dgrad', [gyh, w4t, torch.zeros(B, Cin, H, W), B, Cin, Cout, H, W], [2], tol=5e-5)
+    ws = workspace(K.upconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
+    poison_lds(K)
+    run_both(K, 'upconv3x3_wgrad', [a, gyh, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0], [2], tol=1e-4, scratch=[3])
+    x, gy = rnd(B, Cin, 2 * H, 2 * W, seed=5), rnd(B, Cout, H, W, seed=6)
+    w4, wpp = torch.zeros(Cout, Cin, 4, 4), torch.zeros(4, Cin, Cout, 2, 2)
+    E.poolconv3x3_weights(w, w4, wpp, Cout, Cin)
+    if K.poolconv3x3_supported(B, Cin, Cout, H, W):
+        poison_lds(K)
+        run_both(K, 'poolconv3x3_fwd', [x, w4, b, None, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W], [4], tol=5e-5)
+        poison_lds(K)
+        run_both(K, 'poolconv3x3_dgrad', [gy, wpp, torch.zeros(B, Cin, 2 * H, 2 * W), B, Cin, Cout, H, W], [2], tol=5e-5)
+    ws = workspace(K.poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
+    poison_lds(K)
+    run_both(K, 'poolconv3x3_wgrad', [x, gy, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0], [2], tol=1e-4, scratch=[3])
+
+
 UPCONV_SHAPES = [(2, 16, 16, 16, 16), (3, 8, 20, 8, 8), (2, 32, 16, 64, 64), (4, 128, 128, 4, 4), (2, 128, 64, 16, 16), (2, 5, 7, 6, 10),
                  (8, 64, 32, 32, 32), (1, 16, 3, 33, 20), (64, 128, 128, 4, 4),
                  # enough low-resolution tiles for the all-phases-in-one kernel (aligned, 16x16 planes, ragged)
