@@ -73,6 +73,7 @@ struct Shape {
   int B, Cin, Cout, H, W;
   int oy = 0, ox = 0;      // KS code 2: first tap row / column inside the 3x3 halo
   int os = 1, py = 0, px = 0;   // output written to an (os*H) x (os*W) plane at rows os*h + py, columns os*w + px
+  int prio = 0;                 // LDS-DMA kernels: serial sections at wave priority 3, MFMA blocks at 0 (see conv_dma_kernel)
 };
 
 struct TileCoord {
@@ -644,9 +645,10 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
 #ifdef TG_DIAG_STAMPS
   const uint64_t st_begin = __builtin_amdgcn_s_memtime();
 #endif
-  // Wave priority: the short serial sections (setup, DMA issue, barrier, epilogue) run ahead of the other waves' MFMA streams.
-  // A young wave otherwise gets the vector issue port only when no older wave has an MFMA waiting (stamps: 8 k cycles of
-  // setup for ~200 instructions on the 128^2 layers, 4 k with this); +1.5 % over the layer set, up to +4.5 % per layer.
+  // TG_DMA_PRIO=1 (off by default): the short serial sections (setup, DMA issue, barrier, epilogue) at wave priority 3, the
+  // MFMA blocks at 0.  A young wave otherwise gets the vector issue port only when no older wave has an MFMA waiting
+  // (stamps: 8 k cycles of setup for ~200 instructions on the 128^2 layers, 4 k with this) -- but the MFMA phases stretch by
+  // what the serial sections gain: 0 ... +1.4 % over the layer set depending on the device, not a win worth a default.
   const bool prio = (xcd_swizzle & 32) != 0;
   if (prio) __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63, wave = wave_index();
@@ -1140,6 +1142,7 @@ conv_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
   __shared__ __attribute__((aligned(16))) float lds[LDSF];
 
   const int lane = threadIdx.x & 63, wave = wave_index();
+  if (s.prio) __builtin_amdgcn_s_setprio(3);
   const int j = lane & 15, h = lane >> 4;
   const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CKW;
   const int split = blockIdx.x;
@@ -1200,6 +1203,7 @@ conv_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
   auto compute = [&](const float* buf) {
     const float* pl = buf;
     const float* gl = buf + PBUF;
+    if (s.prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       constexpr int PPI = G::TH * G::TW;
@@ -1217,6 +1221,7 @@ conv_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
     }
+    if (s.prio) __builtin_amdgcn_s_setprio(3);
   };
 
   if constexpr (DB) {
@@ -1736,6 +1741,7 @@ conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t,
   constexpr int REDF = WK ? 4 * NT * 4 * 64 : 0, NBUF = DB ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[(NBUF * BUF > REDF) ? NBUF * BUF : REDF];
   const int lane = threadIdx.x & 63, wave = wave_index();
+  if (s.prio) __builtin_amdgcn_s_setprio(3);
   const int j = lane & 15, h = lane >> 4;
   int bid = blockIdx.x;
   if (xcd_swizzle) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
@@ -1810,6 +1816,7 @@ conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t,
     }
     const float* pl = lds + buf * BUF;
     const float* wl = pl + PBUF;
+    if (s.prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const float a = wl[lane_a + t];
@@ -1817,6 +1824,7 @@ conv_upT_dma_kernel(const float* __restrict__ gy, const float* __restrict__ w4t,
       for (int n = 0; n < NT; ++n)
         acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[lane_b[n] + (t >> 2) * P::PWS + (t & 3)], acc[0][n], 0, 0, 0);
     }
+    if (s.prio) __builtin_amdgcn_s_setprio(3);
     if (DB) buf ^= 1;
   }
   if constexpr (WK) {
@@ -1853,6 +1861,7 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
   constexpr int REDF = WK ? 4 * 2 * NT * 4 * 64 : 0, NBUF = DB ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float lds[(NBUF * BUF > REDF) ? NBUF * BUF : REDF];
   const int lane = threadIdx.x & 63, wave = wave_index();
+  if (s.prio) __builtin_amdgcn_s_setprio(3);
   const int j = lane & 15, h = lane >> 4;
   int bid = blockIdx.x;
   if (xcd_swizzle) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
@@ -1931,6 +1940,7 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
     }
     const float* pl = lds + buf * BUF;
     const float* wl = pl + PBUF;
+    if (s.prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int gi = 0; gi < NG / GSTEP; ++gi) {
       const int g = gi * GSTEP;
@@ -1954,6 +1964,7 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
             }
         }
     }
+    if (s.prio) __builtin_amdgcn_s_setprio(3);
     if (DB) buf ^= 1;
   }
   if constexpr (WK) {
@@ -2128,6 +2139,7 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
   constexpr int RED = 4 * NT * 4 * 64;
   __shared__ __attribute__((aligned(16))) float lds[BUF > RED ? BUF : RED];
   const int lane = threadIdx.x & 63, wave = wave_index();
+  if (s.prio) __builtin_amdgcn_s_setprio(3);
   const int j = lane & 15, h = lane >> 4;
   const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CKW;
   const int split = blockIdx.x;
@@ -2177,6 +2189,7 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
     __syncthreads();
     const float* pl = lds;
     const float* gl = lds + PBUF;
+    if (s.prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int pg = 4 * g;
@@ -2185,6 +2198,7 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[colbase[n] + lane_b + goff], acc[n], 0, 0, 0);
     }
+    if (s.prio) __builtin_amdgcn_s_setprio(3);
   }
   __syncthreads();
   float* red = lds;
@@ -2311,12 +2325,14 @@ static inline int64_t s2_min_wgs(GeoId g) { return g == GEO_8 ? 128 : 256; }
 
 // stride-2 transpose form: 8x8 planes that give fewer than 256 four-image tiles run as single-image K-split tiles
 static bool s2_dma_ok(const void* x, const void* w, const Shape& s, int hi_channels);
+static int dma_prio();
 static bool s2_single_buffer();
 
 static void launch_upT(GeoId g, const float* x, const float* w4, const float* bias, const float* residual, float* y, Shape s,
                        int vx, int vw, hipStream_t st) {
   const int cot = (s.Cout + 15) / 16;
   if (vx && vw && s2_dma_ok(x, w4, s, s.Cin)) {            // LDS-DMA staged forms
+    s.prio = dma_prio();
     if (g == GEO_8 && (int64_t)geo_tiles(g, s.B, s.H, s.W) * cot < 256) {
       const int t = num_tiles<G8k>(s.B, s.H, s.W);
       conv_upT_dma_kernel<G8k, true><<<dim3(t, cot), CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, t % 8 == 0);
@@ -2349,6 +2365,7 @@ static void launch_upfwd(GeoId g, const float* x, const float* wp, const float* 
                          int vx, int vw, hipStream_t st) {
   const int cot = (s.Cout + 15) / 16;
   if (vx && vw && s2_dma_ok(x, wp, s, 0)) {
+    s.prio = dma_prio();
     if (g == GEO_8 && (int64_t)geo_tiles(g, s.B, s.H, s.W) * cot < 256) {
       const int t = num_tiles<G8k>(s.B, s.H, s.W);
       conv_upfwd_dma_kernel<G8k, true><<<dim3(t, cot), CT_THREADS, 0, st>>>(x, wp, bias, residual, y, s, t % 8 == 0);
@@ -2417,7 +2434,7 @@ int launch_fwd_geo(const float* x, const float* w, const float* bias, const floa
 struct DmaKnobs { int enable, tile, ck, ksplit, wgrad, wgrad_db, s2, db, diag, prio; };
 static const DmaKnobs& dma_knobs() {
   static const DmaKnobs k = [] {
-    DmaKnobs d{1, 0, 0, 1, 1, 0, 1, 1, 0, 1};
+    DmaKnobs d{1, 0, 0, 1, 1, 0, 1, 1, 0, 0};
     if (const char* e = getenv("TG_DMA_PRIO")) d.prio = atoi(e);
     if (const char* e = getenv("TG_DMA_DIAG")) d.diag = atoi(e) & 6;
     if (const char* e = getenv("TG_DMA_DB")) d.db = atoi(e);
@@ -2445,6 +2462,7 @@ static bool s2_dma_ok(const void* x, const void* w, const Shape& s, int hi_chann
 }
 
 static bool s2_single_buffer() { return dma_knobs().db == 0; }
+static int dma_prio() { return dma_knobs().prio; }
 
 template <class G, int CK, bool DGRAD>
 static bool launch_dma_geo(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
@@ -2559,6 +2577,7 @@ int launch_wgrad_geo(const float* x, const float* gy, float* part, float* bias_p
     constexpr int CKW = WgCfg<3>::CKW;
     constexpr int buf1 = (dma_pad(CKW * DPatch<G>::CPC) + dma_pad(16 * WGD_GYQ)) * 16, buf2 = (dma_pad(CKW * DPatch<G>::CPC) + dma_pad(32 * WGD_GYQ)) * 16;   // bytes, MTW 1 / 2
     if (k.enable && k.wgrad && vx && vg && small) {
+      s.prio = k.prio;
       // (two buffers -- the next tile in flight under this tile's MFMAs -- measured slower at every shape of the 128 px step:
       // they halve the workgroups per CU; kept behind TG_DMA_WGRAD_DB=1 for wider layers)
       const bool db = k.wgrad_db == 1 || (k.wgrad_db < 0 && p.tiles >= 2 * p.S && (int64_t)p.S * p.co_tiles * p.ci_chunks <= 600);
@@ -2708,6 +2727,7 @@ static int s2_wgrad(const float* hi, const float* lo, float* gw, float* ws, size
   dim3 grid(S, lo_tiles, hi_chunks);
   const int vh = plane_vec_ok(hi, 2 * W), vl = plane_vec_ok(lo, W);
   if (vh && vl && dma_knobs().enable && dma_knobs().wgrad && (int64_t)B * (Chi > Clo ? Chi : Clo) * H * W * 16 < (1ll << 31)) {
+    s.prio = dma_knobs().prio;
     TG_S2_DISPATCH(g, conv_wgrad_s2_dma_kernel, hi, lo, ws, s, tiles, S);
   } else {
     TG_S2_DISPATCH(g, conv_wgrad_s2_kernel, hi, lo, ws, s, tiles, S, vh, vl);
