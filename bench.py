@@ -79,7 +79,7 @@ class KernelTimer:
         self._saved = {}
 
     def __enter__(self):
-        for name in ('conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad', 'bn_train_stats', 'bn_act_fwd', 'bn_act_bwd',
+        for name in ('conv2d_fwd', 'conv2d_fwd_up2res', 'conv2d_dgrad', 'conv2d_wgrad', 'bn_train_stats', 'bn_act_fwd', 'bn_act_bwd',
                      'bn_act_dbwd', 'gemm', 'softmax_fwd', 'softmax_bwd', 'softmax_dbwd', 'up2x', 'pool2',
                      'bilinear_half_fwd', 'bilinear_half_bwd', 'add', 'channel_sum', 'adam_step', 'ema', 'attn_fwd', 'attn_bwd', 'bn_train_fwd',
                      'maxpool2_fwd', 'maxpool2_bwd', 'scale_add_dev', 'dot', 'scale_dev', 'mul', 'lrelu_bwd', 'tanh_fwd', 'tanh_bwd',
@@ -138,7 +138,12 @@ class KernelTimer:
         for (name, args, _, _), ms in zip(records, times):
             flops = 0.0
             nbytes = 0.0
-            if name in CONV_DIMS:
+            if name == 'conv2d_fwd_up2res':       # a 3x3 forward conv whose residual is read at half the resolution
+                B, Cin, Cout, H, W = args[5:10]
+                flops = 2.0 * B * Cin * Cout * H * W * 9
+                nbytes = 4.0 * (B * Cin * H * W + B * Cout * H * W + Cin * Cout * 9) + 1.0 * B * Cout * H * W
+                name = 'conv2d_fwd'
+            elif name in CONV_DIMS:
                 B, Cin, Cout, H, W, ks = args[CONV_DIMS[name]]
                 flops = 2.0 * B * Cin * Cout * H * W * ks * ks
                 # every operand once: input, output (or the two activations of wgrad) and the filter
@@ -152,7 +157,7 @@ class KernelTimer:
                 flops = 2.0 * B * Cin * Cout * H * W * 16
                 hi = Cin if name.startswith('poolconv') else Cout      # channels of the high-resolution (2H x 2W) tensor
                 nbytes = 4.0 * (B * hi * 4 * H * W + B * (Cin + Cout - hi) * H * W + Cin * Cout * 16)
-            if name in ('conv2d_fwd', 'conv2d_dgrad') and args[CONV_DIMS[name]][5] == 1:
+            if name in ('conv2d_fwd', 'conv2d_dgrad') and len(args) >= CONV_DIMS[name].stop and args[CONV_DIMS[name]][5] == 1:
                 name = name + '_1x1'         # bandwidth-bound (AI = Cin Cout / (2 (Cin + Cout)) FLOP/B << the MFMA ridge)
             d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             d['ms'] += ms

@@ -42,6 +42,12 @@ const char* tg_arch(void);
 int tg_conv2d_fwd(const float* x, const float* w, const float* bias /*nullable*/,
                   const float* residual /*nullable: y = conv + bias + residual (x + h, generator.py:62)*/,
                   float* y, int B, int Cin, int Cout, int H, int W, int ks, void* stream);
+/* The generator block's `h + up(project(x))` (generator.py:52-62: x = F.interpolate(x, scale_factor=2) first, then
+ * convs(x) + project_input(x)): the 1x1 projection commutes with nearest-neighbour upsampling, so the shortcut stays at
+ * HALF the resolution and the last 3x3 conv adds it upsampled on the fly: y = conv3x3(x) + bias + up2x(residual_lo),
+ * residual_lo is (B, Cout, H/2, W/2); H, W even.  No high-resolution copy of the shortcut is ever written. */
+int tg_conv2d_fwd_up2res(const float* x, const float* w, const float* bias /*nullable*/, const float* residual_lo,
+                         float* y, int B, int Cin, int Cout, int H, int W, void* stream);
 /* conv3x3(nearest_up2x(a)) + bias [+ residual] without the upsampled tensor (generator.py:52-58: the first 3x3
  * conv of every generator block reads an upsampled activation).  Output pixel (2i+dy, 2j+dx) only sees a 2x2 block
  * of source pixels, so the layer is four 2x2-tap convolutions at the LOW resolution with row/column-summed filters:

@@ -74,6 +74,7 @@ struct Shape {
   int oy = 0, ox = 0;      // KS code 2: first tap row / column inside the 3x3 halo
   int os = 1, py = 0, px = 0;   // output written to an (os*H) x (os*W) plane at rows os*h + py, columns os*w + px
   int prio = 0;                 // LDS-DMA kernels: serial sections at wave priority 3, MFMA blocks at 0 (see conv_dma_kernel)
+  int res_up = 0;               // 1: `residual` is (B, Cout, H/2, W/2) and is added nearest-neighbour upsampled (os == 1, H, W even)
 };
 
 struct TileCoord {
@@ -364,7 +365,11 @@ struct FwdCore {
         const int q = j & 3;
         const int64_t tile0w = ((((int64_t)tc.b0 * s.Cout + co0) * s.H + tc.h0) * s.W + tc.w0) * 4;
         char* ybw = reinterpret_cast<char*>(y) + tile0w;
-        const char* rbw = reinterpret_cast<const char*>(residual) + tile0w;
+        // res_up: the residual lives at half the resolution (tile origins are even, so the halved coordinates split the same way)
+        const int Wr = s.W >> 1;
+        const uint32_t HWr = HW >> 2;
+        const int64_t tile0r = ((((int64_t)tc.b0 * s.Cout + co0) * (s.H >> 1) + (tc.h0 >> 1)) * Wr + (tc.w0 >> 1)) * 4;
+        const char* rbw = reinterpret_cast<const char*>(residual) + (s.res_up ? tile0r : tile0w);
         constexpr int NQW = WK ? 4 : 1;
 #pragma unroll
         for (int qq = 0; qq < NQW; ++qq) {
@@ -397,8 +402,14 @@ struct FwdCore {
                 const uint32_t off = (__umul24(__umul24(img, s.Cout) + row, HW) + __umul24(pr, s.W) + pc) << 2;
                 float4 o = make_float4(t0 + bvw, t1 + bvw, t2 + bvw, t3 + bvw);
                 if (residual) {
-                  const float4 rr = *reinterpret_cast<const float4*>(rbw + off);
-                  o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                  if (s.res_up) {
+                    const uint32_t offr = (__umul24(__umul24(img, s.Cout) + row, HWr) + __umul24(pr >> 1, Wr) + (pc >> 1)) << 2;
+                    const float2 rr = *reinterpret_cast<const float2*>(rbw + offr);
+                    o.x += rr.x; o.y += rr.x; o.z += rr.y; o.w += rr.y;
+                  } else {
+                    const float4 rr = *reinterpret_cast<const float4*>(rbw + off);
+                    o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                  }
                 }
                 *reinterpret_cast<float4*>(ybw + off) = o;
               }
@@ -409,7 +420,10 @@ struct FwdCore {
     }
     const int64_t tile0 = ((((int64_t)tc.b0 * s.Cout + co0) * (s.H * s.os) + tc.h0 * s.os + s.py) * Wo + tc.w0 * s.os + s.px) * 4;
     char* ybase = reinterpret_cast<char*>(y) + tile0;
-    const char* rbase = reinterpret_cast<const char*>(residual) + tile0;
+    const int Wr = s.W >> 1;
+    const uint32_t HWr = (uint32_t)(s.H >> 1) * Wr;
+    const int64_t tile0r = ((((int64_t)tc.b0 * s.Cout + co0) * (s.H >> 1) + (tc.h0 >> 1)) * Wr + (tc.w0 >> 1)) * 4;
+    const char* rbase = reinterpret_cast<const char*>(residual) + (s.res_up ? tile0r : tile0);
     const char* bbase = reinterpret_cast<const char*>(bias + co0);
     const uint32_t lane_row = __umul24(4 * h, HW);
     constexpr int NR = WK ? NREG / 4 : NREG;      // registers this wave stores per (m, n): WK waves take a quarter each
@@ -452,7 +466,11 @@ struct FwdCore {
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
               const int rc = row_of(m, qq * NR + k);
-              if (co0 + rc + 4 * h < s.Cout) o[m][k] = *reinterpret_cast<const float*>(rbase + ((lane_off + (uint32_t)rc * HW) << 2));
+              if (co0 + rc + 4 * h < s.Cout) {
+                const uint32_t ro = s.res_up ? __umul24(__umul24(img, s.Cout) + 4 * h + rc, HWr) + __umul24(pr >> 1, Wr) + (pc >> 1)
+                                             : lane_off + (uint32_t)rc * HW;
+                o[m][k] = *reinterpret_cast<const float*>(rbase + (ro << 2));
+              }
             }
         }
 #pragma unroll
@@ -2643,6 +2661,16 @@ int tg_conv2d_fwd(const float* x, const float* w, const float* bias, const float
   Shape s{B, Cin, Cout, H, W};
   return ks == 3 ? launch_fwd<3, false>(x, w, bias, residual, y, s, tg_stream(stream))
                  : launch_fwd<1, false>(x, w, bias, residual, y, s, tg_stream(stream));
+}
+
+int tg_conv2d_fwd_up2res(const float* x, const float* w, const float* bias, const float* residual_lo, float* y, int B, int Cin,
+                         int Cout, int H, int W, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(w); TG_CHECK_PTR(y); TG_CHECK_PTR(residual_lo);
+  if (int rc = check_shape(B, Cin, Cout, H, W, 3)) return rc;
+  if ((H & 1) || (W & 1)) return TG_EUNSUPPORTED;
+  Shape s{B, Cin, Cout, H, W};
+  s.res_up = 1;
+  return launch_fwd<3, false>(x, w, bias, residual_lo, y, s, tg_stream(stream));
 }
 
 int tg_upconv3x3_weights(const float* w, float* wp, int Cout, int Cin, void* stream) {

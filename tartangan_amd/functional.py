@@ -95,19 +95,26 @@ def _param_grads_wanted():
 
 # =========================================================================== conv
 class _ConvFwd(Function):
-    """y = conv(x, w) + bias [+ residual]; the residual add of the reference's blocks (x + h) rides in the epilogue."""
+    """y = conv(x, w) + bias [+ residual]; the residual add of the reference's blocks (x + h) rides in the epilogue.
+    ``residual_up``: the residual has half the resolution and is added nearest-neighbour upsampled (tg_conv2d_fwd_up2res)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual=None):
+    def forward(ctx, x, w, bias, residual=None, residual_up=False):
         x, w = x.contiguous(), w.contiguous()
         B, Cin, H, W = x.shape
         Cout, ks = w.shape[0], w.shape[2]
         y = x.new_empty(B, Cout, H, W)
         if residual is not None:
             residual = residual.contiguous()
-        K().conv2d_fwd(x, w, bias, residual, y, B, Cin, Cout, H, W, ks)
+        if residual_up:
+            if residual is None or ks != 3 or tuple(residual.shape) != (B, Cout, H // 2, W // 2) or H % 2 or W % 2:
+                raise RuntimeError('residual_up needs a (B, Cout, H/2, W/2) residual on a 3x3 convolution of an even plane')
+            K().conv2d_fwd_up2res(x, w, bias, residual, y, B, Cin, Cout, H, W)
+        else:
+            K().conv2d_fwd(x, w, bias, residual, y, B, Cin, Cout, H, W, ks)
         ctx.save_for_backward(x, w, bias)
         ctx.has_residual = residual is not None
+        ctx.residual_up = residual_up
         return y
 
     @staticmethod
@@ -127,7 +134,10 @@ class _ConvFwd(Function):
                 gw = _ConvWgrad.apply(x, gy, w.shape[2])
             if need_b:
                 gb = _ChannelSum.apply(gy)
-        return gx, gw, gb, (gy if ctx.has_residual and ctx.needs_input_grad[3] else None)
+        gres = None
+        if ctx.has_residual and ctx.needs_input_grad[3]:
+            gres = _Pool2.apply(gy, 1.0) if ctx.residual_up else gy      # transpose of the nearest-neighbour upsampling: 2x2 sums
+        return gx, gw, gb, gres, None
 
 
 class _ConvDgrad(Function):
@@ -275,9 +285,10 @@ class _ChannelBcast(Function):
         return _ChannelSum.apply(g), None
 
 
-def conv2d(x, weight, bias=None, residual=None):
-    """3x3 (pad 1) or 1x1 (pad 0) stride-1 convolution, NCHW fp32; optional fused ``+ residual``."""
-    return _ConvFwd.apply(x, weight, bias, residual)
+def conv2d(x, weight, bias=None, residual=None, residual_up=False):
+    """3x3 (pad 1) or 1x1 (pad 0) stride-1 convolution, NCHW fp32; optional fused ``+ residual`` (``residual_up``: a half-resolution
+    residual, added nearest-neighbour upsampled by the 3x3 kernel's epilogue)."""
+    return _ConvFwd.apply(x, weight, bias, residual, residual_up)
 
 
 # =========================================================================== GEMM

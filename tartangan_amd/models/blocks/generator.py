@@ -55,11 +55,13 @@ class ResidualGeneratorBlock(nn.Module):
             else:
                 xa = xs = x
             a = mods[0].forward_act(xa, mods[1].negative_slope, replicate=4)
-            shortcut = TF.upsample_nearest2x(xs if self.project_input is None else run_layers(self.project_input, xs))
+            # the shortcut stays at the low resolution too: the block's last 3x3 conv adds it upsampled in its epilogue
+            # (tg_conv2d_fwd_up2res), no high-resolution copy is written or read
+            shortcut = xs if self.project_input is None else run_layers(self.project_input, xs)
             conv = mods[2]
             if type(conv) is Conv2d and conv.kernel_size == (3, 3) and len(mods) > 3 and TF.upconv3x3_pays(a, conv.weight):
-                return run_layers(self.convs[3:], TF.upconv3x3(a, conv.weight, conv.bias), residual=shortcut)
-            return run_layers(self.convs[2:], TF.upsample_nearest2x(a), residual=shortcut)
+                return run_layers(self.convs[3:], TF.upconv3x3(a, conv.weight, conv.bias), residual=shortcut, residual_up=True)
+            return run_layers(self.convs[2:], TF.upsample_nearest2x(a), residual=shortcut, residual_up=True)
         xs, xu = TF.fork_upsample_nearest2x(x)           # one graph node for both uses (functional._ForkUp2x)
         shortcut = xs if self.project_input is None else run_layers(self.project_input, xs)
         return run_layers(self.convs, xu, residual=shortcut)

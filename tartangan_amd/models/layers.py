@@ -117,11 +117,15 @@ class BatchNorm2d(nn.BatchNorm2d):
         return self._run(x, slope, replicate)
 
 
-def run_layers(seq, x, residual=None):
+def run_layers(seq, x, residual=None, residual_up=False):
     """Apply an ``nn.Sequential`` the way ``Sequential.forward`` would, fusing each
     (BatchNorm2d, LeakyReLU) pair into one kernel pass.  ``residual`` (the block's shortcut) is added to the
-    result; when the last layer is a Conv2d or an AvgPool2d the add rides in that kernel's epilogue."""
+    result; when the last layer is a Conv2d or an AvgPool2d the add rides in that kernel's epilogue.
+    ``residual_up``: the shortcut is given at half the resolution of the result (generator blocks); a final 3x3 Conv2d adds it
+    upsampled on the fly, anything else gets it upsampled first."""
     mods = list(seq)
+    if residual_up and not (mods and type(mods[-1]) is Conv2d and mods[-1].kernel_size == (3, 3)):
+        residual, residual_up = TF.upsample_nearest2x(residual), False
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -138,7 +142,7 @@ def run_layers(seq, x, residual=None):
             i += 2
             continue
         if last and residual is not None and type(m) is Conv2d:
-            x, residual = TF.conv2d(x, m.weight, m.bias, residual), None
+            x, residual = TF.conv2d(x, m.weight, m.bias, residual, residual_up), None
         elif last and residual is not None and type(m) is AvgPool2d:
             x, residual = TF.avg_pool2(x, residual), None
         else:

@@ -28,6 +28,11 @@ class Emulator:
         y.copy_(r if residual is None else _v(residual, B, Cout, H, W) + r)
         return 0
 
+    def conv2d_fwd_up2res(self, x, w, bias, residual_lo, y, B, Cin, Cout, H, W):
+        r = F.conv2d(_v(x, B, Cin, H, W), _v(w, Cout, Cin, 3, 3), bias, padding=1)
+        y.copy_(F.interpolate(_v(residual_lo, B, Cout, H // 2, W // 2), scale_factor=2) + r)
+        return 0
+
     def upconv3x3_weights(self, w, wp, Cout, Cin):
         k = _v(w, Cout, Cin, 3, 3)
         out = _v(wp, 4, Cout, Cin, 2, 2)

@@ -145,6 +145,19 @@ def test_stride2_step_shapes_full_batch_after_lds_poison(K, shape):
     run_both(K, 'poolconv3x3_wgrad', [x, gy, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0], [2], tol=1e-4, scratch=[3])
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64, 64), (3, 32, 16, 32, 32), (2, 64, 32, 16, 16), (5, 128, 128, 8, 8), (20, 128, 128, 4, 4),
+                                   (2, 8, 12, 20, 36), (2, 20, 24, 10, 6), (3, 5, 7, 34, 18), (64, 16, 16, 128, 128), (64, 64, 64, 32, 32), (64, 128, 128, 16, 16),
+                                   (64, 128, 128, 8, 8)])
+def test_conv_fwd_with_half_resolution_residual(K, shape):
+    """y = conv3x3(x) + bias + up2x(residual_lo): the generator block's shortcut added from the low resolution."""
+    B, Cin, Cout, H, W = shape
+    x, w, b = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, scale=0.2), rnd(Cout)
+    r = rnd(B, Cout, H // 2, W // 2, seed=7)
+    poison_lds(K)
+    run_both(K, 'conv2d_fwd_up2res', [x, w, b, r, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W], [4], tol=2e-5)
+    run_both(K, 'conv2d_fwd_up2res', [x, w, None, r, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W], [4], tol=2e-5)
+
+
 UPCONV_SHAPES = [(2, 16, 16, 16, 16), (3, 8, 20, 8, 8), (2, 32, 16, 64, 64), (4, 128, 128, 4, 4), (2, 128, 64, 16, 16), (2, 5, 7, 6, 10),
                  (8, 64, 32, 32, 32), (1, 16, 3, 33, 20), (64, 128, 128, 4, 4),
                  # enough low-resolution tiles for the all-phases-in-one kernel (aligned, 16x16 planes, ragged)

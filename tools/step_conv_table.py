@@ -21,7 +21,10 @@ agg = collections.defaultdict(lambda: [0.0, 0, 0.0])
 other = collections.defaultdict(lambda: [0.0, 0])
 for name, args, a, b in kt.records:
     ms = a.elapsed_time(b)
-    if name in bench.CONV_DIMS:
+    if name == 'conv2d_fwd_up2res':
+        Bb, Cin, Cout, H, W = args[5:10]
+        key, fl = (name, Cin, Cout, H, 3), 2.0 * Bb * Cin * Cout * H * W * 9
+    elif name in bench.CONV_DIMS:
         Bb, Cin, Cout, H, W, ks = args[bench.CONV_DIMS[name]]
         key, fl = (name, Cin, Cout, H, ks), 2.0 * Bb * Cin * Cout * H * W * ks * ks
     elif name in S2:
