@@ -156,6 +156,13 @@ def test_conv_fwd_with_half_resolution_residual(K, shape):
     poison_lds(K)
     run_both(K, 'conv2d_fwd_up2res', [x, w, b, r, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W], [4], tol=2e-5)
     run_both(K, 'conv2d_fwd_up2res', [x, w, None, r, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W], [4], tol=2e-5)
+    # the same bits as the materialised form: up2x, then the plain fused-residual kernel
+    xd, wd, bd, rd = x.cuda(), w.cuda(), b.cuda(), r.cuda()
+    y1, y2, ru = torch.empty(B, Cout, H, W, device='cuda'), torch.empty(B, Cout, H, W, device='cuda'), torch.empty(B, Cout, H, W, device='cuda')
+    K.conv2d_fwd_up2res(xd, wd, bd, rd, y1, B, Cin, Cout, H, W)
+    K.up2x(rd, ru, 1.0, B * Cout, H // 2, W // 2)
+    K.conv2d_fwd(xd, wd, bd, ru, y2, B, Cin, Cout, H, W, 3)
+    assert torch.equal(y1, y2)
 
 
 UPCONV_SHAPES = [(2, 16, 16, 16, 16), (3, 8, 20, 8, 8), (2, 32, 16, 64, 64), (4, 128, 128, 4, 4), (2, 128, 64, 16, 16), (2, 5, 7, 6, 10),
