@@ -792,7 +792,9 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
 #endif
     const float* pl = lds + buf * BUF;
     const float* wl = pl + PBUF;
-    if (xcd_swizzle & 4) { buf ^= 1; continue; }               // diagnostic build only: no MFMAs
+#ifdef TG_DIAG_STAMPS
+    if (xcd_swizzle & 4) { buf ^= 1; continue; }               // TG_DMA_DIAG=4 (stage isolation, wrong results): no MFMAs
+#endif
     if (prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int gi = 0; gi < NG / (WK ? 4 : 1); ++gi) {
@@ -854,7 +856,9 @@ conv_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const 
           acc[m][n][r] = (red[e] + red[PW_ + e]) + (red[2 * PW_ + e] + red[3 * PW_ + e]);
         }
   }
-  if ((xcd_swizzle & 2) && acc[0][0][0] != 12345.678f) return;   // diagnostic build only: no epilogue
+#ifdef TG_DIAG_STAMPS
+  if ((xcd_swizzle & 2) && acc[0][0][0] != 12345.678f) return;   // TG_DMA_DIAG=2 (stage isolation, wrong results): no epilogue
+#endif
   Core::epilogue(acc, bias, residual, y, s, tc, co0, pix0, j, h, wave);
 #ifdef TG_DIAG_STAMPS
   {   // workgroup life: entry -> loop, loop -> stores issued, ... -> stores acknowledged
@@ -2454,7 +2458,9 @@ static const DmaKnobs& dma_knobs() {
   static const DmaKnobs k = [] {
     DmaKnobs d{1, 0, 0, 1, 1, 0, 1, 1, 0, 0};
     if (const char* e = getenv("TG_DMA_PRIO")) d.prio = atoi(e);
-    if (const char* e = getenv("TG_DMA_DIAG")) d.diag = atoi(e) & 6;
+#ifdef TG_DIAG_STAMPS
+    if (const char* e = getenv("TG_DMA_DIAG")) d.diag = atoi(e) & 6;       // stage isolation: the diagnostic build only
+#endif
     if (const char* e = getenv("TG_DMA_DB")) d.db = atoi(e);
     if (const char* e = getenv("TG_DMA_S2")) d.s2 = atoi(e);
     if (const char* e = getenv("TG_DMA_WGRAD")) d.wgrad = atoi(e);
