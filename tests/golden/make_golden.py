@@ -82,6 +82,7 @@ from tartangan.trainers.iqn import IQNTrainer  # noqa: E402
 GAN_CONFIGS['64:1'] = GAN_CONFIGS['64']._replace(attention=(1,))
 GAN_CONFIGS['128:3'] = GAN_CONFIGS['128']._replace(attention=(3,))
 GAN_CONFIGS['32:2'] = GAN_CONFIGS['32']._replace(attention=(2,))
+GAN_CONFIGS['256:3'] = GAN_CONFIGS['256']._replace(attention=(3,))
 
 CASES = {
     # name: (config, trainer, batch, steps)
@@ -108,6 +109,11 @@ CASES = {
     'c64a1_cnn_b4_scale075': ('64:1', 'cnn', 4, 2, dict(model_scale=0.75)),
     'c32_cnn_b8_id': ('32', 'cnn', 8, 2, dict(norm='id')),
     'c512thin_test_cnn_b2': ('512thin-test', 'cnn', 2, 1),
+    # the remaining families of pluggan.GAN_CONFIGS: the smallest, a 256 px one (with and without attention), the wide one
+    'c16_cnn_b16': ('16', 'cnn', 16, 2),
+    'c256a3_cnn_b2': ('256:3', 'cnn', 2, 1),
+    'c256_iqn_b2': ('256', 'iqn', 2, 1),
+    'c128big_cnn_b2': ('128big', 'cnn', 2, 1),
 }
 
 WEIGHT_SEED = 7
