@@ -34,10 +34,12 @@ gemm_big_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float
   constexpr int AROWS = TA ? GB_BK : GB_BM, AQ = ARS / 4;         // rows, chunks per row
   constexpr int ACH = AROWS * AQ, BCH = GB_BK * (GB_BN / 4);
   constexpr int NVA = (ACH + GB_T - 1) / GB_T, NVB = (BCH + GB_T - 1) / GB_T;
+  static_assert(ACH % 64 == 0 && BCH % 64 == 0, "LDS regions of whole wave pieces");
   constexpr int ABUF = ACH * 4, BBUF = BCH * 4, BUF = ABUF + BBUF;
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (scalar wave index: an LDS-DMA may only sit under wave-uniform conditions, see dma_pad in conv.hip / DESIGN.md section 7)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   // workgroup -> tile: an XCD (block id mod 8) takes a band of tile rows, so that its L2 keeps the A panels
@@ -81,13 +83,13 @@ gemm_big_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float
     for (int v = 0; v < NVA; ++v) {
       uint32_t off = aoff[v];
       if (kvalid < GB_BK) off = (arow[v] < kvalid) ? off : GB_OOB;       // (K % 4 == 0: a chunk is all in or all out)
-      if ((v + 1) * GB_T <= ACH || v * GB_T + (int)threadIdx.x < ACH) gb_dma16(ra, buf + (v * GB_T + wave * 64) * 4, off);
+      if ((v + 1) * GB_T <= ACH || v * GB_T + wave * 64 < ACH) gb_dma16(ra, buf + (v * GB_T + wave * 64) * 4, off);
     }
 #pragma unroll
     for (int v = 0; v < NVB; ++v) {
       uint32_t off = boff[v];
       if (kvalid < GB_BK) off = (brow[v] < kvalid) ? off : GB_OOB;
-      if ((v + 1) * GB_T <= BCH || v * GB_T + (int)threadIdx.x < BCH) gb_dma16(rb, buf + ABUF + (v * GB_T + wave * 64) * 4, off);
+      if ((v + 1) * GB_T <= BCH || v * GB_T + wave * 64 < BCH) gb_dma16(rb, buf + ABUF + (v * GB_T + wave * 64) * 4, off);
     }
     ab += astep; abytes -= astep;
     bb += bstep; bbytes -= bstep;

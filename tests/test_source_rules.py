@@ -9,11 +9,14 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CONV = os.path.join(os.path.dirname(HERE), 'tartangan_amd', 'csrc', 'conv.hip')
-SCALAR_TOKEN = re.compile(r'^(i|wave|CT_THREADS|PCHP|WCHP|GCHP|\d+)$')
+SCALAR_TOKEN = re.compile(r'^(i|v|wave|CT_THREADS|GB_T|PCHP|WCHP|GCHP|ACH|BCH|\d+)$')
 
 
-def _guards():
-    lines = open(CONV).read().split('\n')
+FID = os.path.join(os.path.dirname(HERE), 'tartangan_amd', 'csrc', 'fid.hip')
+
+
+def _guards(path=CONV):
+    lines = open(path).read().split('\n')
     out = []
     for n, line in enumerate(lines):
         if 'dma16(' not in line or '__device__' in line:
@@ -21,7 +24,7 @@ def _guards():
         stmt = line.strip()
         if not stmt.startswith('if'):                      # the guard sits on the line above
             stmt = re.sub(r'\s*//.*$', '', lines[n - 1].strip()) + ' ' + stmt
-        m = re.match(r'if \((.*)\)\s+dma16\(', stmt)
+        m = re.match(r'if \((.*)\)\s+(?:gb_)?dma16\(', stmt)
         out.append((n + 1, m.group(1) if m else None, stmt))
     return out
 
@@ -29,11 +32,13 @@ def _guards():
 def test_every_lds_dma_sits_under_a_scalar_condition_only():
     guards = _guards()
     assert len(guards) >= 10                               # conv_dma, wgrad, upT, upfwd, s2 wgrad: two regions each
-    for lineno, cond, stmt in guards:
-        assert cond is not None, f'conv.hip:{lineno}: unguarded or unparsable dma16 call: {stmt}'
-        assert 'threadIdx' not in cond and 'lane' not in cond, f'conv.hip:{lineno}: per-lane guard on an LDS-DMA: {cond}'
+    fid = _guards(FID)
+    assert len(fid) == 2                                   # gemm_big_kernel: the A and the B panel
+    for lineno, cond, stmt in guards + fid:
+        assert cond is not None, f'csrc line {lineno}: unguarded or unparsable dma16 call: {stmt}'
+        assert 'threadIdx' not in cond and 'lane' not in cond, f'csrc line {lineno}: per-lane guard on an LDS-DMA: {cond}'
         for tok in re.findall(r'[A-Za-z_]\w*|\d+', cond):
-            assert SCALAR_TOKEN.match(tok), f'conv.hip:{lineno}: `{tok}` in the guard of an LDS-DMA is not known to be wave-uniform: {cond}'
+            assert SCALAR_TOKEN.match(tok), f'csrc line {lineno}: `{tok}` in the guard of an LDS-DMA is not known to be wave-uniform: {cond}'
 
 
 def test_wave_index_is_scalar_where_it_guards_a_dma():
