@@ -2513,7 +2513,10 @@ template <class G, bool DGRAD>
 static bool launch_dma_ksplit(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
   const int64_t tiles = num_tiles<G>(s.B, s.H, s.W);
   const int swz = ((tiles % 8 == 0) ? 1 : 0) | (dma_knobs().prio ? 32 : 0);
-  if (s.Cout % 32 == 0 || s.Cout > 48)
+  // 32-channel tiles only while they still give every CU more than one workgroup: with one (or less) per CU nothing
+  // overlaps a workgroup's DMA waits, and twice as many 16-channel workgroups win (batch 64: 128->128 @4^2 15.9 -> 10.6 us,
+  // 64->128 @8^2 dgrad 15.5 -> 10.2 us, 128->128 @8^2 16.6 -> 16.0 us; 256->256 @8^2, 512 workgroups, stays on 32)
+  if ((s.Cout % 32 == 0 || s.Cout > 48) && tiles * ((s.Cout + 31) / 32) > 256)
     conv_dma_kernel<G, 32, 1, 16, DGRAD><<<dim3(tiles, (s.Cout + 31) / 32), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
   else
     conv_dma_kernel<G, 16, 1, 16, DGRAD><<<dim3(tiles, (s.Cout + 15) / 16), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, swz);
