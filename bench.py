@@ -2,7 +2,9 @@
 """Benchmark: images/sec of the full SA-GAN G+D training step (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...:
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or from a bare shell -- the script then starts the N
+  ranks itself as fresh child processes (self_launch) and relays rank 0's line.
 
 Workload (config.workload): GAN_CONFIGS['128'] with the author's attention placement (3,)
 ("128:3"), tartangan.trainers.cnn step semantics (BCE + R1 penalty 5.0, Adam(0,.999) x2, EMA),
@@ -46,10 +48,10 @@ def parse():
     p.add_argument('--no-kernel-timing', action='store_true')
     p.add_argument('--cpu-batch', type=int, default=None, help='batch of the CPU-baseline sample (default: --batch)')
     p.add_argument('--sync-bn', action='store_true', help='N>1: BatchNorm statistics of the GLOBAL batch (SyncBN)')
-    p.add_argument('--overlap', choices=['off', 'on', 'auto'], default='off',
-                   help='N>1: D-bucket all-reduce on a side stream under the generator forward.  off (default): serial schedule -- '
-                        'the collective is ~40 us of a ~6 ms step, and the side-stream path next to graph replay could only be '
-                        'rehearsed over gloo on this build\'s one-GPU boxes, where it stalls; auto: time both, keep the faster')
+    p.add_argument('--overlap', choices=['off', 'on', 'auto', 'tune'], default='auto',
+                   help='N>1: gradient-bucket all-reduces on a side stream (D bucket under the generator forward).  auto (default): on '
+                        'with RCCL, off with gloo (its host-staged device path stalls next to a replaying graph); off: serial schedule; '
+                        'tune: time both, keep the faster')
     p.add_argument('--backend', default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the DP code path)')
     p.add_argument('--share-gpu', action='store_true', help='rehearsal only: every rank uses cuda:0')
     return p.parse_args()
@@ -235,31 +237,98 @@ def _cpu_sample(config, kind, batch, threads, n):
         torch.set_num_threads(prev)
 
 
+def physical_cores():
+    """(physical cores, logical CPUs this process may run on)."""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = set()
+    try:
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                phys = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                core = line.split(':')[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return (min(len(cores), logical) if cores else logical), logical
+
+
 def cpu_baseline(config, kind, batch):
     """The CPU oracle (kind "port": oracle/sagan_cpu.py, plain PyTorch CPU fp32, pinned to the reference by the golden
-    fixtures) timed on this host: the GPU line's own workload and batch on every host thread, and -- for comparison
-    with BASELINE.md's 8-thread survey numbers -- a short 8-thread sample."""
-    cores = torch.get_num_threads()
-    n = 3
-    value = _cpu_sample(config, kind, batch, cores, n)
-    out = dict(value=round(value, 3), unit='images/s', cores=cores, kind='port',
-               sample=f'{n} timed steps (+1 untimed) of the {config} {kind} step at batch {batch} on {cores} host threads, '
-                      f'oracle/sagan_cpu.py (plain PyTorch CPU fp32)')
-    if cores > 8:
-        b8 = min(batch, 16)
-        out['threads_8'] = dict(value=round(_cpu_sample(config, kind, b8, 8, 2), 3), unit='images/s', cores=8,
-                                sample=f'2 timed steps (+1 untimed) at batch {b8} on 8 threads')
-    return out
+    fixtures) timed on this host at the GPU line's own workload and batch.  `value` is the BEST of a short sweep over
+    thread counts {8, 16, 32, 64, physical cores} (each: 1 untimed + 1 timed step; more threads than the oracle's small
+    layers can use only add contention -- round 2's all-threads sample lost to its own 8-thread run), `cores` the thread
+    count that achieved it; the whole sweep is ~20-40 s of host time."""
+    phys, logical = physical_cores()
+    counts = sorted({c for c in (8, 16, 32, 64, phys) if c <= max(phys, 8) and c <= max(logical, 8)})
+    sweep, worse = {}, 0
+    for c in counts:
+        v = _cpu_sample(config, kind, batch, c, 1)
+        if sweep and v < max(sweep.values()):
+            worse += 1
+        sweep[c] = round(v, 3)
+        if worse >= 2:                   # past the knee: larger counts only cost bench time
+            break
+    best = max(sweep, key=sweep.get)
+    return dict(value=sweep[best], unit='images/s', cores=best, kind='port', physical_cores=phys, logical_cpus=logical,
+                thread_sweep={str(k): v for k, v in sweep.items()},
+                sample=f'best of a thread sweep {list(sweep)}: 1 timed step (+1 untimed) each of the {config} {kind} step at batch '
+                       f'{batch}, oracle/sagan_cpu.py (plain PyTorch CPU fp32); host has {phys} physical cores / {logical} logical CPUs')
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE): start the N ranks as FRESH child processes through
+    torch.distributed.run and relay rank 0's JSON line.  This parent never touches the GPU (no torch.cuda call, no HIP
+    library load), so nothing GPU-initialised is ever re-exec'ed or forked.  Exit code = the children's."""
+    import subprocess
+
+    def run(extra):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__), *sys.argv[1:], *extra]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: what RCCL needs on this host driver
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // a.gpus)))
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+        for ln in proc.stdout.splitlines():
+            if not ln.startswith('{"metric"'):
+                print(ln, file=sys.stderr)
+        return proc.returncode, lines
+
+    rc, lines = run([])
+    if (rc != 0 or not lines) and a.overlap != 'off':
+        # one fallback, for a collective library that fails FAST with the side-stream schedule: the serial schedule
+        # (a run that hangs is not retried -- the driver's limit ends it)
+        print(f'bench.py: ranks exited with {rc}; retrying once with --overlap off', file=sys.stderr)
+        rc, lines = run(['--overlap', 'off'])
+    if rc == 0 and len(lines) == 1:
+        print(lines[0], flush=True)
+        return 0
+    print(f'bench.py: ranks exited with {rc}, {len(lines)} result line(s)', file=sys.stderr)
+    return rc or 1
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+        sys.exit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch one rank per GPU '
+                 f'(python bench.py --gpus N starts them itself)')
     if a.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -277,7 +346,8 @@ def main():
         from tartangan_amd.parallel import DataParallel
         if not a.eager:
             tr.enable_graphs()
-        dp = DataParallel(tr, sync_bn=a.sync_bn, overlap=(a.overlap == 'on'))
+        overlap = {'on': True, 'off': False}.get(a.overlap, a.backend == 'nccl')
+        dp = DataParallel(tr, sync_bn=a.sync_bn, overlap=overlap)
     elif not a.eager:
         tr.enable_graphs()
     size = tr.g.max_size
@@ -289,7 +359,7 @@ def main():
     warm = max(a.warmup, 0 if a.eager else 2)  # graph mode: step 1 eager (records RNG plan), step 2 captures
     for _ in range(warm):
         logs = tr.train_batch(imgs)
-    if world > 1 and a.overlap == 'auto':       # (untimed) keep the side-stream all-reduce only if it is not slower here
+    if world > 1 and a.overlap == 'tune':       # (untimed) keep the side-stream all-reduce only if it is not slower here
         dp.autotune_overlap(lambda: tr.train_batch(imgs))
 
     def fence():
@@ -337,7 +407,9 @@ def main():
                                                       f' ({"global-batch (synchronised)" if a.sync_bn else "local-batch"} BatchNorm, '
                                                       f'flat-bucket {dp.collective_name} all-reduce x2'
                                                       f'{", D bucket on a side stream under the G forward" if dp.overlap else ""})'),
-                       'hip_graphs': not a.eager},
+                       'hip_graphs': not a.eager,
+                       **({} if world == 1 else {'rccl_ranks': dist.get_world_size(), 'collective_backend': dist.get_backend(),
+                                                 'sync_bn': bool(a.sync_bn), 'overlap': bool(dp.overlap)})},
             'final_losses': {k: round(v, 6) for k, v in logs.items()},
         }
         flop_img = FLOP_PER_IMAGE.get(a.config)

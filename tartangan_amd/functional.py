@@ -699,6 +699,8 @@ class _BNAct(Function):
                 extra = None
             _bn_bwd_into(gz, x, mean, invstd, gamma, beta, ctx.slope, ctx.training, gx, sink_g, sink_b, 1, ctx.sync, extra)
             return (gx, None, None) + nones
+        # (a second-order gradient is only ever parked inside grads_into_buckets(), i.e. for the branch above)
+        assert ctx.cell.pending is None, 'BatchNorm: a parked second-order input gradient would be dropped'
         gx, gg, gb = _BNActBwd.apply(gz, x, gamma, beta, mean, invstd, ctx.slope, ctx.training,
                                      ctx.needs_input_grad[0], ctx.sync, ctx.cell)
         return (gx, gg, gb) + nones

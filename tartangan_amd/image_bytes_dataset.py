@@ -72,10 +72,15 @@ class ImageBytesDataset:
         return self.batch([int(idx)])[0]
 
     def loader(self, batch_size, shuffle=True, drop_last=True, rank=0, world=1):
-        """One epoch of GLOBAL batches of ``batch_size * world`` images; yields this rank's rows.  The permutation is drawn
-        the way ``RandomSampler`` does (a fresh generator seeded with one int64 taken from the default CPU generator), so a
-        seeded run consumes the default generator like the reference's loader; every rank draws the same permutation."""
+        """One epoch of GLOBAL batches of ``batch_size * world`` images; yields this rank's rows.  The default CPU
+        generator is consumed exactly like ``iter(DataLoader(...))`` of this torch does -- the iterator's base seed, then
+        ``RandomSampler``'s seed for a private permutation generator, then per image the two crop offsets -- pinned against a
+        real ``torch.utils.data.DataLoader`` in tests/test_input_and_components.py; every rank draws the same stream."""
         n = len(self)
+        # creating a DataLoader iterator draws its ``_base_seed`` from the default generator (one int64 ``random_()``,
+        # torch/utils/data/dataloader.py ``_BaseDataLoaderIter.__init__``) -- once per epoch, shuffled or not, BEFORE the
+        # sampler draws anything; a loader that skipped it would diverge from the reference's stream at the first batch
+        torch.empty((), dtype=torch.int64).random_()
         if shuffle:
             seed = int(torch.empty((), dtype=torch.int64).random_().item())
             order = torch.randperm(n, generator=torch.Generator().manual_seed(seed))

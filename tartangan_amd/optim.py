@@ -162,12 +162,49 @@ class FusedAdam:
                     exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone())
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd['step'])
+        """Accepts this class's own ``state_dict()`` and the stock ``torch.optim.Adam`` layout ``{'state': {i: {'step',
+        'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{'lr', 'betas', 'eps', 'params'}]}`` -- what ``cp_model.state_dict()``
+        returns for the ``opt_d.pt`` / ``opt_g.pt`` a reference run pickled (components/model_checkpoint.py:39-45): the
+        per-parameter moments are packed into the flat buckets in parameter order.  Validated before anything is
+        written, so a layout this optimiser cannot take leaves it untouched."""
+        if 'param_groups' in sd and 'state' in sd:
+            sd = self._from_torch_adam(sd)
+        step, exp_avg, exp_avg_sq = int(sd['step']), sd['exp_avg'], sd['exp_avg_sq']
+        if exp_avg.numel() != self.exp_avg.numel() or exp_avg_sq.numel() != self.exp_avg_sq.numel():
+            raise ValueError(f'FusedAdam.load_state_dict: moments of {exp_avg.numel()} floats for a bucket of {self.exp_avg.numel()}')
+        self.step_count = step
         self.lr = float(sd.get('lr', self.lr))
         self.betas = tuple(float(b) for b in sd.get('betas', self.betas))
         self.eps = float(sd.get('eps', self.eps))
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        self.exp_avg.copy_(exp_avg)
+        self.exp_avg_sq.copy_(exp_avg_sq)
+
+    def _from_torch_adam(self, sd):
+        groups = sd['param_groups']
+        if len(groups) != 1:
+            raise ValueError('FusedAdam.load_state_dict: one parameter group expected (the trainers build Adam over model.parameters())')
+        group, state = groups[0], sd['state']
+        if group.get('amsgrad') or group.get('weight_decay'):
+            raise ValueError('FusedAdam.load_state_dict: amsgrad / weight_decay are outside the hot path (trainers/cnn.py:84-85)')
+        params = list(self.module.parameters())
+        ids = list(group['params'])
+        if len(ids) != len(params):
+            raise ValueError(f'FusedAdam.load_state_dict: {len(ids)} parameters in the checkpoint, {len(params)} in the module')
+        zeros = [torch.zeros_like(p, device='cpu') for p in params]
+        avg, sq, steps = list(zeros), list(zeros), set()
+        for k, (pid, p) in enumerate(zip(ids, params)):
+            st = state.get(pid)
+            if st is None:                       # a parameter that never received a gradient has no state yet
+                continue
+            if tuple(st['exp_avg'].shape) != tuple(p.shape):
+                raise ValueError(f'FusedAdam.load_state_dict: parameter {k} has shape {tuple(p.shape)}, its moments {tuple(st["exp_avg"].shape)}')
+            avg[k], sq[k] = st['exp_avg'].detach().float().cpu(), st['exp_avg_sq'].detach().float().cpu()
+            steps.add(int(st['step']))
+        if len(steps) > 1:
+            raise ValueError(f'FusedAdam.load_state_dict: per-parameter step counts differ ({sorted(steps)}); one flat bucket has one step')
+        lr = group['lr']
+        return dict(step=steps.pop() if steps else 0, lr=float(lr), betas=tuple(group['betas']), eps=group['eps'],
+                    exp_avg=pack(avg, self.flat), exp_avg_sq=pack(sq, self.flat))
 
 
 def ema_update(target_module, source_module, lr):

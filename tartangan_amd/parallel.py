@@ -9,8 +9,9 @@ At these sizes the collectives are latency-bound; there is nothing to bucket fur
 Overlap (``overlap=True``, the default on a device): both all-reduces are issued on a side stream
 that waits for the producing backward, and are joined only where their result is consumed --
 the D bucket right before D's Adam step, i.e. after the G phase's generator forward (which needs
-no discriminator weights; trainers.cnn._g_forward), the G bucket right before G's Adam step, i.e.
-after the host has drawn and uploaded the next step's latents.  The serial schedule
+no discriminator weights; trainers.cnn._g_forward), the G bucket right before G's Adam step (in the default schedule that is
+immediately: the collective is exposed; ``trainers.cnn`` with ``defer_g_update`` hides it under the next step's D(real)
+forward and R1 first-order pass, which read no generator weight).  The serial schedule
 (``overlap=False``) issues the same collectives on the compute stream; both give bit-identical
 parameters (tests/test_dp_gloo.py).
 
@@ -55,8 +56,15 @@ class DataParallel:
         trainer._route_rng_through_feed()       # IQN taus must come through the feed to be sliced per rank
         if not getattr(trainer, '_graph_requested', False):
             feed.mode = 'off'                   # eager: draw (and slice) the global tensors on every call
+        self.bn_group = None
         if self.sync_bn and self.world > 1:
-            handle = TF.SyncGroup(process_group, self.world)
+            # SyncBN's collectives sit INSIDE the passes (with RCCL: captured into the step's graphs) while a gradient bucket
+            # may be in flight on the side stream.  Two collectives of ONE communicator issued from independent streams can
+            # reach the device in a different order on different ranks, which RCCL/NCCL does not allow (it may hang) -- so
+            # the BatchNorm sums get a communicator of their own; the bucket all-reduces keep ``process_group``.
+            ranks = dist.get_process_group_ranks(process_group) if process_group is not None else None
+            self.bn_group = dist.new_group(ranks=ranks) if self.overlap else process_group
+            handle = TF.SyncGroup(self.bn_group, self.world)
             for net in (trainer.g, trainer.d):
                 for m in net.modules():
                     if isinstance(m, BatchNorm2d):

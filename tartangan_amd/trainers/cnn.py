@@ -143,10 +143,14 @@ class CNNTrainer(Trainer):
         self.d.train()
         dp = self.data_parallel
         graphs_ok = dp is None or dp.capturable      # SyncBN over gloo: host-side collectives inside the passes
-        if graphs_ok and (getattr(self, '_graphs', None) is not None or getattr(self, '_graph_requested', False)):
-            vals = self._train_batch_graphed(imgs)
-        else:
-            vals = self._train_batch_eager(imgs)
+        self._in_step = True
+        try:
+            if graphs_ok and (getattr(self, '_graphs', None) is not None or getattr(self, '_graph_requested', False)):
+                vals = self._train_batch_graphed(imgs)
+            else:
+                vals = self._train_batch_eager(imgs)
+        finally:
+            self._in_step = False
         self.steps += 1
         vals = torch.stack([v for v in vals if v is not None]).tolist()     # one device->host read
         return dict(g_loss=vals[0], d_loss=vals[1], gp=vals[2] if len(vals) > 2 else 0.)
@@ -182,7 +186,7 @@ class CNNTrainer(Trainer):
             self.rng_feed.mode = 'record'
         iqn = getattr(getattr(self.d, 'to_output', None), 'iqn', None)
         if iqn is not None:
-            iqn.tau_source = lambda rows, q: self.rng_feed.draw('tau', rows, q)
+            iqn.tau_source = lambda rows, q: self._draw('tau', rows, q)
 
     def _capture(self, imgs):
         feed = self.rng_feed

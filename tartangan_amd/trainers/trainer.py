@@ -80,6 +80,7 @@ class Trainer:
         self.data_parallel = None
         self.rng_feed = RngFeed(self.device)
         self.rng_feed.mode = 'off'
+        self._in_step = False        # True only inside train_batch (and graph capture): draws then go through the feed
 
     # ------------------------------------------------------------------ hot-path helpers
     @property
@@ -91,7 +92,17 @@ class Trainer:
         a seed gives the same z on any device."""
         if n is None:
             n = self.args.batch_size
-        return self.rng_feed.draw('z', n, self.gan_config.latent_dims)
+        return self._draw('z', n, self.gan_config.latent_dims)
+
+    def _draw(self, kind, rows, cols):
+        """Random inputs of the step go through ``RngFeed`` (recorded plan, static buffers, per-rank slices).  A draw made
+        OUTSIDE a step -- a component's ``sample_z(32)`` at train begin, a user's ``trainer.d(x)`` -- is the reference's
+        plain ``torch.randn(n, latent).to(device)`` (trainer.py:153-156) / ``torch.rand(rows, 1)`` (iqn.py:105-108): a fresh
+        tensor, never part of the recorded plan, the same values on every rank."""
+        if self._in_step:
+            return self.rng_feed.draw(kind, rows, cols)
+        val = torch.randn(rows, cols) if kind == 'z' else torch.rand(rows, 1)
+        return val.to(self.device)
 
     def sample_g(self, n=None, target_g=False, **g_kwargs):
         z = self.sample_z(n)

@@ -37,23 +37,66 @@ def emulated():
     backend._set_backend_for_testing(prev)
 
 
+class _IndexAndCrop(torch.utils.data.Dataset):
+    """Stand-in for ImageBytesDataset + RandomCrop under a REAL DataLoader: returns (index, y0, x0) and consumes the default
+    generator like torchvision's RandomCrop.get_params (two randint draws per image unless the crop is the whole image)."""
+
+    def __init__(self, n, stored, crop):
+        self.n, self.stored, self.crop = n, stored, crop
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        y0 = x0 = 0
+        if self.stored != self.crop:
+            y0 = int(torch.randint(0, self.stored - self.crop + 1, size=(1,)).item())
+            x0 = int(torch.randint(0, self.stored - self.crop + 1, size=(1,)).item())
+        return torch.tensor([i, y0, x0])
+
+
+def _real_dataloader_stream(n, batch, stored, crop, seed, epochs=1, shuffle=True):
+    """-> (image order, crop offsets, next default-generator draw) of a real torch DataLoader over ``epochs`` epochs."""
+    torch.manual_seed(seed)
+    order, crops = [], []
+    dl = torch.utils.data.DataLoader(_IndexAndCrop(n, stored, crop), batch_size=batch, shuffle=shuffle, drop_last=True)
+    for _ in range(epochs):
+        for rows in dl:
+            order += rows[:, 0].tolist()
+            crops += rows[:, 1:].tolist()
+    return order, crops, float(torch.rand(1))
+
+
+@pytest.mark.parametrize('shuffle', [True, False])
+def test_loader_consumes_the_default_generator_like_a_real_dataloader(tmp_path, emulated, shuffle):
+    """Two epochs, with random crops: same image order, same crop offsets, same generator state afterwards as
+    ``torch.utils.data.DataLoader(shuffle, drop_last=True)`` (whose iterator draws a base seed before the sampler's)."""
+    from tartangan_amd.image_bytes_dataset import ImageBytesDataset
+    path, images = make_archive(tmp_path, n=22, size=40)
+    ds = ImageBytesDataset.from_path(path, crop_size=32, device='cpu')
+    order, crops, after = _real_dataloader_stream(22, 8, 40, 32, seed=7, epochs=2, shuffle=shuffle)
+    torch.manual_seed(7)
+    got = [b for _ in range(2) for b in ds.loader(8, shuffle=shuffle)]
+    assert float(torch.rand(1)) == after
+    assert len(got) == 4
+    want = [reference_transform(images[i], y0, x0, 32) for i, (y0, x0) in zip(order, crops)]
+    assert torch.equal(torch.cat(got), torch.stack(want))
+
+
 def test_loader_order_sharding_and_rng_consumption(tmp_path, emulated):
     from tartangan_amd.image_bytes_dataset import ImageBytesDataset
     path, images = make_archive(tmp_path)
     ds = ImageBytesDataset.from_path(path, device='cpu')
     assert len(ds) == 40 and ds.image_size == 32
     assert torch.equal(ds[3], reference_transform(images[3]))
-    # the permutation a DataLoader(shuffle=True) would draw: RandomSampler seeds a private generator from the default one
-    torch.manual_seed(5)
-    seed = int(torch.empty((), dtype=torch.int64).random_().item())
-    order = torch.randperm(40, generator=torch.Generator().manual_seed(seed))
-    after = float(torch.rand(1))
+    # what a real DataLoader(shuffle=True, drop_last=True) (trainers/trainer.py:84-86) draws from the default generator
+    order, _, after = _real_dataloader_stream(40, 16, 32, 32, seed=5)
     torch.manual_seed(5)
     batches = list(ds.loader(16))
     assert float(torch.rand(1)) == after                          # same consumption of the default generator
     assert len(batches) == 2                                      # drop_last
     for k, got in enumerate(batches):
-        want = torch.stack([reference_transform(images[i]) for i in order[16 * k:16 * k + 16].tolist()])
+        want = torch.stack([reference_transform(images[i]) for i in order[16 * k:16 * k + 16]])
         assert torch.equal(got, want)
     # two ranks: each global batch of 16 split into rows [0, 8) and [8, 16)
     for rank in range(2):
@@ -206,3 +249,81 @@ def test_sampler_consumes_rng_like_the_reference(tmp_path, emulated):
     assert Image.open(f'{sm.sample_root}/sample_0.png').size == (8 * 34 + 2, 4 * 34 + 2)      # 32 images, 8 per row, padding 2
     x = torch.tensor([-2.0, -1.0, 0.0, 1.0, 3.0]).view(1, 1, 1, 5)
     assert image_grid_uint8(x, padding=0).reshape(-1).tolist() == [0, 0, 128, 255, 255]
+
+
+def test_reference_adam_checkpoint_loads_into_the_flat_optimiser(tmp_path, emulated):
+    """opt_d.pt / opt_g.pt of a reference run are pickled ``torch.optim.Adam`` objects (model_checkpoint.py:39-45);
+    ``load_checkpoint`` hands their ``state_dict()`` ({'state', 'param_groups'}) to ``FusedAdam.load_state_dict``: moments
+    are packed into the flat buckets, step / lr / betas / eps taken over, and the next step equals torch's."""
+    from tartangan_amd.optim import FusedAdam, param_offsets
+    tr = _trainer(tmp_path)
+    net = tr.d
+    stock_params = [torch.nn.Parameter(p.detach().clone()) for p in net.parameters()]
+    stock = torch.optim.Adam(stock_params, lr=3e-4, betas=(0., 0.999))
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(2):
+        for p in stock_params:
+            p.grad = torch.randn(p.shape, generator=gen)
+        stock.step()
+    mine = FusedAdam(net, lr=1e-3, betas=(0.5, 0.9))
+    mine.load_state_dict(torch.optim.Adam(stock_params).state_dict() | stock.state_dict())
+    assert mine.step_count == 2 and mine.lr == 3e-4 and mine.betas == (0., 0.999)
+    offs, _ = param_offsets(list(net.parameters()))
+    for k, (p, o) in enumerate(zip(stock_params, offs)):
+        st = stock.state[p]
+        assert torch.equal(mine.exp_avg[o:o + p.numel()].view(p.shape), st['exp_avg']), k
+        assert torch.equal(mine.exp_avg_sq[o:o + p.numel()].view(p.shape), st['exp_avg_sq']), k
+    # one more step on both from the same weights and gradients
+    with torch.no_grad():
+        for p, q in zip(net.parameters(), stock_params):
+            p.copy_(q)
+    for p, q in zip(net.parameters(), stock_params):
+        q.grad = torch.randn(q.shape, generator=gen)
+        p.grad.copy_(q.grad)
+    stock.step()
+    mine.step()
+    for k, (p, q) in enumerate(zip(net.parameters(), stock_params)):
+        assert torch.allclose(p, q, rtol=1e-6, atol=1e-8), k
+    # a layout the flat optimiser cannot take leaves it untouched
+    bad = stock.state_dict()
+    bad['param_groups'][0]['amsgrad'] = True
+    with pytest.raises(ValueError):
+        mine.load_state_dict(bad)
+    assert mine.step_count == 3
+
+
+def test_draws_outside_a_step_bypass_the_recorded_rng_plan(tmp_path, emulated):
+    """ImageSamplerComponent.on_train_begin calls sample_z(32) and the first output sample_z(4) BETWEEN steps; with the
+    step's draws routed through RngFeed (graph replay, data parallel) those must not enter the recorded plan, must not hand
+    out the step's static buffers and must not be rank-sliced."""
+    from tartangan_amd.trainers.components import ImageSamplerComponent
+    tr = _trainer(tmp_path)
+    tr._route_rng_through_feed()                      # what enable_graphs() / DataParallel do (record mode)
+    sm = ImageSamplerComponent(tr.args)
+    tr.attach(sm)
+    torch.manual_seed(11)
+    sm.on_train_begin(0, {})
+    assert tr.rng_feed.plan == []
+    imgs = synthetic_images(4, 32, 1)
+    logs = [tr.train_batch(imgs)]
+    plan = list(tr.rng_feed.plan)
+    assert plan and ('z', 32, tr.gan_config.latent_dims) not in plan and len(plan) == 5
+    sm.on_batch_end(0, {})                            # sample_z(4) == the batch size: must not alias the step's z buffer
+    assert tr.rng_feed.plan == plan
+    assert all(sm._latent_grid_samples.data_ptr() != b.data_ptr() for b in tr.rng_feed.static)
+    tr.rng_feed.mode = 'serve'
+    tr.rng_feed.refill()
+    logs.append(tr.train_batch(imgs))
+    after = float(torch.rand(1))
+
+    ref = _trainer(tmp_path)                          # the same run with plain eager draws
+    sm2 = ImageSamplerComponent(ref.args)
+    ref.attach(sm2)
+    torch.manual_seed(11)
+    sm2.on_train_begin(0, {})
+    want = [ref.train_batch(imgs)]
+    sm2.on_batch_end(0, {})
+    want.append(ref.train_batch(imgs))
+    assert float(torch.rand(1)) == after
+    assert logs == want
+    assert torch.equal(sm.progress_samples, sm2.progress_samples)
