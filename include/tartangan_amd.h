@@ -166,6 +166,23 @@ int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const floa
                   int B, int C, int HW, int accumulate /* ggamma, gbeta += */,
                   const float* gx_add /*nullable: gx = ... + gx_add, a second gradient of x folded into the pass*/,
                   void* stream);
+/* ---- grouped forms: ONE tensor of groups*B images normalised per (group, channel).  trainers/cnn.py:122-123 run the
+ * discriminator on the real and on the fake batch as two forwards with the same weights; here both halves travel through
+ * the network as one tensor of 2B images (convolutions are per image), and BatchNorm keeps the statistics of each half:
+ * group g = images [g*B, (g+1)*B).  mean / invstd are [groups][C]; the running statistics are updated once per group, in
+ * group order (exactly what the two forwards leave behind), *num_batches_tracked += groups; ggamma / gbeta are the sums
+ * over all groups.  Workspace: tg_bn_workspace(B, groups*C, HW) bytes.  groups = 1 is tg_bn_train_fwd / tg_bn_act_bwd.
+ * gx_add (nullable) holds the first add_groups*B images only (the R1 second-order gradient exists for the real half). */
+int tg_bn_train_fwd_groups(const float* x, float* mean, float* invstd,
+                           float* running_mean /*nullable*/, float* running_var /*nullable*/,
+                           int64_t* num_batches_tracked /*nullable*/, const float* gamma, const float* beta,
+                           float slope, float momentum, float eps, float* z, float* workspace,
+                           int groups, int B, int C, int HW, int replicate, void* stream);
+int tg_bn_act_bwd_groups(const float* gz, const float* x, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, float slope, int training,
+                         float* gx /*nullable*/, float* ggamma, float* gbeta, float* workspace,
+                         int groups, int B, int C, int HW, int accumulate,
+                         const float* gx_add /*nullable*/, int add_groups, void* stream);
 /* second backward of the training-mode map (gz, x, gamma) -> (gx, ggamma, gbeta)
  * (NativeBatchNormBackwardBackward0; R1 penalty path, models/losses.py:23-26).
  * v = adjoint of gx, vgamma/vbeta = adjoints of ggamma/gbeta (nullable = 0).   */
@@ -269,6 +286,10 @@ int tg_elu_fwd(const float* x, float alpha, float scale, float* y, int64_t n, vo
 int tg_elu_bwd(const float* g, const float* x, float alpha, float scale, int order, float* out, int64_t n,
                void* stream);
 int tg_fill(float* x, float value, int64_t n, void* stream);
+/* dst (B, Cd, HW) <- src (B, Cs, HW): channels [0, min(Cs, Cd)) copied, channels >= Cs set to `fill`.  Cd = Cs + 1, fill 1:
+ * the all-ones channel that carries the from-RGB bias when discriminator.py:11-22 (1x1) is composed into the first 3x3
+ * (blocks/discriminator.py forward_from_rgb; replaces torch.cat + ones); Cd < Cs: its transpose (drop the channel). */
+int tg_copy_channels(const float* src, float* dst, int B, int Cs, int Cd, int HW, float fill, void* stream);
 
 /* ---------------------------------------------------------------- softmax (attention.py:32) */
 int tg_softmax_fwd(const float* s, float* y, int rows, int cols, void* stream);

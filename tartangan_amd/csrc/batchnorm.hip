@@ -12,6 +12,7 @@
 namespace {
 
 using planes::BLOCK;
+using planes::Chan;
 
 // workspace layout: [C*S*5] doubles of partial sums, then [C*COEF] floats of per-channel coefficients
 constexpr int COEF = 8;
@@ -37,7 +38,7 @@ struct RedStats {
   const float* x;
   int C, HW;
   float pivot;
-  __device__ void init(int c) { pivot = x[(int64_t)c * HW]; }   // first element of the channel: shift against cancellation
+  __device__ void init(const Chan& ch) { pivot = x[ch.base + (int64_t)ch.c * HW]; }   // first element of the (group's) channel: shift against cancellation
   using V = float4;
   __device__ V ld4(int64_t off) const { return *reinterpret_cast<const float4*>(x + off); }
   __device__ void acc(const V& v, float* a) {
@@ -52,27 +53,45 @@ struct RedStats {
   }
 };
 
+// mean / variance of virtual channel vc (group g's channel c) from the stage-1 partials; wave-collective
+__device__ __forceinline__ void finish_stats(const double* __restrict__ partial, const float* __restrict__ x, int vc, int c, int64_t base,
+                                             int B, int HW, int S, double& m, double& var) {
+  const double n = (double)B * HW;
+  const double pivot = (double)x[base + (int64_t)c * HW];
+  const double s1 = planes::gather(partial, vc, S, 2, 0) / n;
+  const double s2 = planes::gather(partial, vc, S, 2, 1) / n;
+  m = pivot + s1;
+  var = s2 - s1 * s1;
+  if (var < 0.0) var = 0.0;
+}
+// one running-statistics update, rounded to fp32 like a separate BatchNorm call would leave it
+__device__ __forceinline__ void running_update(float& rmf, float& rvf, double m, double var, double n, int rep, float momentum) {
+  const double nr = n * rep;                     // element count of the tensor these statistics stand for
+  const double unbiased = nr > 1.0 ? var * (nr / (nr - 1.0)) : var;
+  rmf = (float)((1.0 - (double)momentum) * (double)rmf + (double)momentum * m);
+  rvf = (float)((1.0 - (double)momentum) * (double)rvf + (double)momentum * unbiased);
+}
+
+// one wave per CHANNEL; the groups are finished one after the other, so the running statistics see them in order
 __global__ void stats_stage2(const double* __restrict__ partial, const float* __restrict__ x, float* __restrict__ mean,
                              float* __restrict__ invstd, float* __restrict__ rm, float* __restrict__ rv,
-                             int64_t* __restrict__ nbt, float momentum, float eps, int B, int C, int HW, int S, int rep) {
-  const int c = blockIdx.x;                       // one wave per channel
-  const double n = (double)B * HW;
-  const double pivot = (double)x[(int64_t)c * HW];
-  const double s1 = planes::gather(partial, c, S, 2, 0) / n;
-  const double s2 = planes::gather(partial, c, S, 2, 1) / n;
-  if (threadIdx.x != 0) return;
-  if (c == 0 && nbt != nullptr) *nbt += 1;
-  const double m = pivot + s1;
-  double var = s2 - s1 * s1;
-  if (var < 0.0) var = 0.0;
-  mean[c] = (float)m;
-  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (rm != nullptr) {
-    const double nr = n * rep;                     // element count of the tensor these statistics stand for
-    const double unbiased = nr > 1.0 ? var * (nr / (nr - 1.0)) : var;
-    rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * m);
-    rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
+                             int64_t* __restrict__ nbt, float momentum, float eps, int B, int C, int HW, int S, int rep, int G) {
+  const int c = blockIdx.x;
+  float rmf = 0.f, rvf = 0.f;
+  if (rm != nullptr) { rmf = rm[c]; rvf = rv[c]; }
+  for (int g = 0; g < G; ++g) {
+    const int vc = g * C + c;
+    double m, var;
+    finish_stats(partial, x, vc, c, (int64_t)g * B * C * HW, B, HW, S, m, var);
+    if (threadIdx.x == 0) {
+      mean[vc] = (float)m;
+      invstd[vc] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    running_update(rmf, rvf, m, var, (double)B * HW, rep, momentum);
   }
+  if (threadIdx.x != 0) return;
+  if (c == 0 && nbt != nullptr) *nbt += G;
+  if (rm != nullptr) { rm[c] = rmf; rv[c] = rvf; }
 }
 
 __global__ void eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ mean,
@@ -88,12 +107,12 @@ struct FwdBody {
   const float* x; float* z;
   const float *mean, *invstd, *gamma, *beta;
   float slope;
-  __device__ void coeffs(int c, float& a, float& b) const {
-    a = gamma[c] * invstd[c];
-    b = beta[c] - mean[c] * a;
+  __device__ void coeffs(const Chan& ch, float& a, float& b) const {
+    a = gamma[ch.c] * invstd[ch.vc];
+    b = beta[ch.c] - mean[ch.vc] * a;
   }
-  __device__ void vec4(int c, int64_t off) const {
-    float a, b; coeffs(c, a, b);
+  __device__ void vec4(const Chan& ch, int64_t off) const {
+    float a, b; coeffs(ch, a, b);
     const float4 v = *reinterpret_cast<const float4*>(x + off);
     float4 r;
     float y;
@@ -103,8 +122,8 @@ struct FwdBody {
     y = bn_y(v.w, a, b); r.w = y >= 0.f ? y : y * slope;
     *reinterpret_cast<float4*>(z + off) = r;
   }
-  __device__ void one(int c, int64_t off) const {
-    float a, b; coeffs(c, a, b);
+  __device__ void one(const Chan& ch, int64_t off) const {
+    float a, b; coeffs(ch, a, b);
     const float y = bn_y(x[off], a, b);
     z[off] = y >= 0.f ? y : y * slope;
   }
@@ -118,34 +137,37 @@ struct FwdStatsBody {
   int64_t* nbt;
   const float *gamma, *beta;
   float slope, momentum, eps;
-  int B, HW, S, rep;
+  int B, HW, S, rep, C, G;
   float a, b;
-  __device__ void begin(int c, bool lead) {
-    const double n = (double)B * HW;
-    const double pivot = (double)x[(int64_t)c * HW];
-    const double s1 = planes::gather(partial, c, S, 2, 0) / n;
-    const double s2 = planes::gather(partial, c, S, 2, 1) / n;
-    const double m = pivot + s1;
-    double var = s2 - s1 * s1;
-    if (var < 0.0) var = 0.0;
+  __device__ void begin(const Chan& ch, bool lead) {
+    const int c = ch.c;
+    double m, var;
+    finish_stats(partial, x, ch.vc, c, ch.base, B, HW, S, m, var);
     const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
     a = gamma[c] * rf;
     b = beta[c] - mf * a;
-    if (lead && threadIdx.x == 0) {
-      if (c == 0 && nbt != nullptr) *nbt += 1;
-      mean[c] = mf;
-      invstd[c] = rf;
-      if (rm != nullptr) {
-        const double nr = n * rep;
-        const double unbiased = nr > 1.0 ? var * (nr / (nr - 1.0)) : var;
-        rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * m);
-        rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
+    if (!lead) return;                        // (uniform per block)
+    if (threadIdx.x == 0) {
+      if (ch.vc == 0 && nbt != nullptr) *nbt += G;
+      mean[ch.vc] = mf;
+      invstd[ch.vc] = rf;
+    }
+    if (ch.vc == c && rm != nullptr) {
+      // group 0's lead block publishes the running statistics for ALL groups of its channel, in group order (two
+      // forwards of the reference update them real-then-fake); the other groups' sums are a few hundred bytes from L2
+      float rmf = rm[c], rvf = rv[c];
+      running_update(rmf, rvf, m, var, (double)B * HW, rep, momentum);
+      for (int g = 1; g < G; ++g) {
+        double mg, vg;
+        finish_stats(partial, x, g * C + c, c, (int64_t)g * B * C * HW, B, HW, S, mg, vg);
+        running_update(rmf, rvf, mg, vg, (double)B * HW, rep, momentum);
       }
+      if (threadIdx.x == 0) { rm[c] = rmf; rv[c] = rvf; }
     }
   }
   using V = float4;
   __device__ V ld(int64_t off) const { return *reinterpret_cast<const float4*>(x + off); }
-  __device__ void st(int c, int64_t off, const V& v) const {
+  __device__ void st(const Chan&, int64_t off, const V& v) const {
     float4 r;
     float y;
     y = bn_y(v.x, a, b); r.x = y >= 0.f ? y : y * slope;
@@ -162,10 +184,10 @@ struct RedBwd {
   const float *gz, *x, *mean, *invstd, *gamma, *beta;
   float slope;
   float a, b, mu, r;
-  __device__ void init(int c) {
-    r = invstd[c]; mu = mean[c];
-    a = gamma[c] * r;
-    b = beta[c] - mu * a;
+  __device__ void init(const Chan& ch) {
+    r = invstd[ch.vc]; mu = mean[ch.vc];
+    a = gamma[ch.c] * r;
+    b = beta[ch.c] - mu * a;
   }
   __device__ void elem(float g, float xv, float* acc) {
     const float y = bn_y(xv, a, b);
@@ -183,17 +205,25 @@ struct RedBwd {
   __device__ void acc1(int64_t off, float* acc) { elem(gz[off], x[off], acc); }
 };
 
+// one wave per CHANNEL: parameter gradients are the sums over all groups, the input-gradient coefficients per group
 __global__ void bwd_stage2(const double* __restrict__ partial, float* __restrict__ ggamma, float* __restrict__ gbeta,
-                           float* __restrict__ coef, int B, int C, int HW, int S, int accumulate) {
-  const int c = blockIdx.x;                       // one wave per channel
+                           float* __restrict__ coef, int B, int C, int HW, int S, int accumulate, int G) {
+  const int c = blockIdx.x;
   const double n = (double)B * HW;
-  const double sb = planes::gather(partial, c, S, 2, 0);
-  const double sg = planes::gather(partial, c, S, 2, 1);
+  double tb = 0.0, tg = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const int vc = g * C + c;
+    const double sb = planes::gather(partial, vc, S, 2, 0);
+    const double sg = planes::gather(partial, vc, S, 2, 1);
+    tb += sb; tg += sg;
+    if (threadIdx.x == 0) {
+      coef[vc * COEF + 0] = (float)(sb / n);
+      coef[vc * COEF + 1] = (float)(sg / n);
+    }
+  }
   if (threadIdx.x != 0) return;
-  gbeta[c] = (float)sb + (accumulate ? gbeta[c] : 0.f);
-  ggamma[c] = (float)sg + (accumulate ? ggamma[c] : 0.f);
-  coef[c * COEF + 0] = (float)(sb / n);
-  coef[c * COEF + 1] = (float)(sg / n);
+  gbeta[c] = (float)tb + (accumulate ? gbeta[c] : 0.f);
+  ggamma[c] = (float)tg + (accumulate ? ggamma[c] : 0.f);
 }
 
 struct BwdBody {
@@ -201,25 +231,26 @@ struct BwdBody {
   const float *mean, *invstd, *gamma, *beta, *coef;
   float slope; int training;
   const float* add;          // nullable: a second gradient of x (the R1 penalty's second-order term) added in the same pass
+  int add_vc_end;            // ... for the virtual channels below this (the leading groups; `add` holds only their images)
   __device__ float elem(float g, float xv, float a, float b, float mu, float r, float k1, float k2) const {
     const float y = bn_y(xv, a, b);
     const float gyh = y >= 0.f ? g : g * slope;
     return training ? a * (gyh - k1 - ((xv - mu) * r) * k2) : a * gyh;
   }
-  __device__ void vec4(int c, int64_t off) const {
-    const float r = invstd[c], mu = mean[c], a = gamma[c] * r, b = beta[c] - mu * a;
-    const float k1 = coef[c * COEF + 0], k2 = coef[c * COEF + 1];
+  __device__ void vec4(const Chan& ch, int64_t off) const {
+    const float r = invstd[ch.vc], mu = mean[ch.vc], a = gamma[ch.c] * r, b = beta[ch.c] - mu * a;
+    const float k1 = coef[ch.vc * COEF + 0], k2 = coef[ch.vc * COEF + 1];
     const float4 g = *reinterpret_cast<const float4*>(gz + off);
     const float4 v = *reinterpret_cast<const float4*>(x + off);
     float4 o;
     o.x = elem(g.x, v.x, a, b, mu, r, k1, k2); o.y = elem(g.y, v.y, a, b, mu, r, k1, k2);
     o.z = elem(g.z, v.z, a, b, mu, r, k1, k2); o.w = elem(g.w, v.w, a, b, mu, r, k1, k2);
-    if (add) { const float4 t = *reinterpret_cast<const float4*>(add + off); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+    if (add && ch.vc < add_vc_end) { const float4 t = *reinterpret_cast<const float4*>(add + off); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
     *reinterpret_cast<float4*>(gx + off) = o;
   }
-  __device__ void one(int c, int64_t off) const {
-    const float r = invstd[c], mu = mean[c], a = gamma[c] * r, b = beta[c] - mu * a;
-    gx[off] = elem(gz[off], x[off], a, b, mu, r, coef[c * COEF + 0], coef[c * COEF + 1]) + (add ? add[off] : 0.f);
+  __device__ void one(const Chan& ch, int64_t off) const {
+    const float r = invstd[ch.vc], mu = mean[ch.vc], a = gamma[ch.c] * r, b = beta[ch.c] - mu * a;
+    gx[off] = elem(gz[off], x[off], a, b, mu, r, coef[ch.vc * COEF + 0], coef[ch.vc * COEF + 1]) + ((add && ch.vc < add_vc_end) ? add[off] : 0.f);
   }
 };
 
@@ -232,18 +263,29 @@ struct BwdSumsBody {
   float slope; int training, accumulate, B, HW, S;
   float a, b, mu, r, k1, k2;
   const float* add;
-  __device__ void begin(int c, bool lead) {
+  int C, G, add_vc_end;
+  bool use_add;
+  __device__ void begin(const Chan& ch, bool lead) {
+    const int c = ch.c;
     const double n = (double)B * HW;
-    const double sb = planes::gather(partial, c, S, 2, 0);
-    const double sg = planes::gather(partial, c, S, 2, 1);
-    r = invstd[c]; mu = mean[c];
+    const double sb = planes::gather(partial, ch.vc, S, 2, 0);
+    const double sg = planes::gather(partial, ch.vc, S, 2, 1);
+    r = invstd[ch.vc]; mu = mean[ch.vc];
     a = gamma[c] * r;
     b = beta[c] - mu * a;
     k1 = (float)(sb / n);
     k2 = (float)(sg / n);
-    if (lead && threadIdx.x == 0) {
-      gbeta[c] = (float)sb + (accumulate ? gbeta[c] : 0.f);
-      ggamma[c] = (float)sg + (accumulate ? ggamma[c] : 0.f);
+    use_add = add != nullptr && ch.vc < add_vc_end;
+    if (lead && ch.vc == c) {                  // group 0's lead block publishes the parameter gradients: sums over ALL groups
+      double tb = sb, tg = sg;
+      for (int g = 1; g < G; ++g) {
+        tb += planes::gather(partial, g * C + c, S, 2, 0);
+        tg += planes::gather(partial, g * C + c, S, 2, 1);
+      }
+      if (threadIdx.x == 0) {
+        gbeta[c] = (float)tb + (accumulate ? gbeta[c] : 0.f);
+        ggamma[c] = (float)tg + (accumulate ? ggamma[c] : 0.f);
+      }
     }
   }
   __device__ float elem(float g, float xv) const {
@@ -254,9 +296,9 @@ struct BwdSumsBody {
   struct V { float4 g, v, t; };
   __device__ V ld(int64_t off) const {
     return V{*reinterpret_cast<const float4*>(gz + off), *reinterpret_cast<const float4*>(x + off),
-             add ? *reinterpret_cast<const float4*>(add + off) : make_float4(0.f, 0.f, 0.f, 0.f)};
+             use_add ? *reinterpret_cast<const float4*>(add + off) : make_float4(0.f, 0.f, 0.f, 0.f)};
   }
-  __device__ void st(int c, int64_t off, const V& q) const {
+  __device__ void st(const Chan&, int64_t off, const V& q) const {
     float4 o;
     o.x = elem(q.g.x, q.v.x) + q.t.x; o.y = elem(q.g.y, q.v.y) + q.t.y; o.z = elem(q.g.z, q.v.z) + q.t.z; o.w = elem(q.g.w, q.v.w) + q.t.w;
     *reinterpret_cast<float4*>(gx + off) = o;
@@ -269,7 +311,8 @@ struct RedDbwd {
   const float *v, *gz, *x, *mean, *invstd, *gamma, *beta;
   float slope;
   float a, b, mu, r;
-  __device__ void init(int c) {
+  __device__ void init(const Chan& ch) {
+    const int c = ch.c;
     r = invstd[c]; mu = mean[c];
     a = gamma[c] * r;
     b = beta[c] - mu * a;
@@ -335,8 +378,8 @@ struct DbwdBody {
     const float q = -h.gr * (h.cg * vv + h.cv * gyh) + h.vg * gyh;
     o_x = h.r * (q - h.qm - xh * h.qx) - h.k6 * xh;
   }
-  __device__ void vec4(int c, int64_t off) const {
-    const Ch h = load(c);
+  __device__ void vec4(const Chan& ch, int64_t off) const {
+    const Ch h = load(ch.c);
     const float4 w = *reinterpret_cast<const float4*>(v + off);
     const float4 g = *reinterpret_cast<const float4*>(gz + off);
     const float4 q = *reinterpret_cast<const float4*>(x + off);
@@ -346,8 +389,8 @@ struct DbwdBody {
     *reinterpret_cast<float4*>(adj_gz + off) = og;
     *reinterpret_cast<float4*>(adj_x + off) = ox;
   }
-  __device__ void one(int c, int64_t off) const {
-    const Ch h = load(c);
+  __device__ void one(const Chan& ch, int64_t off) const {
+    const Ch h = load(ch.c);
     elem(h, v[off], gz[off], x[off], adj_gz[off], adj_x[off]);
   }
 };
@@ -368,14 +411,14 @@ constexpr int SB = 1024, SPER = SMALL_N / SB;
 struct SmallIdx {
   int64_t off[SPER];
   bool ok[SPER];
-  __device__ __forceinline__ SmallIdx(int B, int C, int HW, int c) {
+  __device__ __forceinline__ SmallIdx(int B, int C, int HW, int c, int64_t base = 0) {
     const int n = B * HW;
 #pragma unroll
     for (int i = 0; i < SPER; ++i) {
       const int e = threadIdx.x + i * SB;
       const int b = e / HW, p = e - b * HW;
       ok[i] = e < n;
-      off[i] = ((int64_t)b * C + c) * HW + p;
+      off[i] = base + ((int64_t)b * C + c) * HW + p;
     }
   }
 };
@@ -392,45 +435,51 @@ __device__ __forceinline__ double block_sum_d1024(double v, double* scratch) {
   return r;
 }
 
+// One workgroup per CHANNEL; its G groups (B images each) are normalised one after the other, so the running statistics
+// are updated in group order.
 __global__ void __launch_bounds__(SB) bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
-                                                          float momentum, float eps, float* __restrict__ z, int B, int C, int HW, int rep) {
+                                                          float momentum, float eps, float* __restrict__ z, int B, int C, int HW, int rep,
+                                                          int G) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
-  const SmallIdx ix(B, C, HW, c);
-  const float pivot = x[(int64_t)c * HW];
-  float xv[SPER];
-#pragma unroll
-  for (int i = 0; i < SPER; ++i) xv[i] = ix.ok[i] ? x[ix.off[i]] : pivot;
-  float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-  for (int i = 0; i < SPER; ++i) { const float d = xv[i] - pivot; a0 += d; a1 += d * d; }
+  float rmf = 0.f, rvf = 0.f;
+  if (rm != nullptr) { rmf = rm[c]; rvf = rv[c]; }
   const double n = (double)B * HW;
-  const double s1 = block_sum_d1024((double)a0, scratch) / n;
-  const double s2 = block_sum_d1024((double)a1, scratch) / n;
-  const double m = (double)pivot + s1;
-  double var = s2 - s1 * s1;
-  if (var < 0.0) var = 0.0;
-  const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
-  if (threadIdx.x == 0) {
-    mean[c] = mf;
-    invstd[c] = rf;
-    if (rm != nullptr) {
-      const double nr = n * rep;
-      const double unbiased = nr > 1.0 ? var * (nr / (nr - 1.0)) : var;
-      rm[c] = (float)((1.0 - (double)momentum) * (double)rm[c] + (double)momentum * m);
-      rv[c] = (float)((1.0 - (double)momentum) * (double)rv[c] + (double)momentum * unbiased);
-    }
-    if (c == 0 && nbt != nullptr) *nbt += 1;
-  }
-  const float a = gamma[c] * rf, b = beta[c] - mf * a;
+  for (int g = 0; g < G; ++g) {
+    const int64_t base = (int64_t)g * B * C * HW;
+    const SmallIdx ix(B, C, HW, c, base);
+    const float pivot = x[base + (int64_t)c * HW];
+    float xv[SPER];
 #pragma unroll
-  for (int i = 0; i < SPER; ++i)
-    if (ix.ok[i]) {
-      const float y = bn_y(xv[i], a, b);
-      z[ix.off[i]] = y >= 0.f ? y : y * slope;
+    for (int i = 0; i < SPER; ++i) xv[i] = ix.ok[i] ? x[ix.off[i]] : pivot;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPER; ++i) { const float d = xv[i] - pivot; a0 += d; a1 += d * d; }
+    const double s1 = block_sum_d1024((double)a0, scratch) / n;
+    const double s2 = block_sum_d1024((double)a1, scratch) / n;
+    const double m = (double)pivot + s1;
+    double var = s2 - s1 * s1;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+      mean[g * C + c] = mf;
+      invstd[g * C + c] = rf;
     }
+    running_update(rmf, rvf, m, var, n, rep, momentum);
+    const float a = gamma[c] * rf, b = beta[c] - mf * a;
+#pragma unroll
+    for (int i = 0; i < SPER; ++i)
+      if (ix.ok[i]) {
+        const float y = bn_y(xv[i], a, b);
+        z[ix.off[i]] = y >= 0.f ? y : y * slope;
+      }
+  }
+  if (threadIdx.x == 0) {
+    if (rm != nullptr) { rm[c] = rmf; rv[c] = rvf; }
+    if (c == 0 && nbt != nullptr) *nbt += G;
+  }
 }
 
 __global__ void __launch_bounds__(SB) bn_small_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ x,
@@ -438,33 +487,39 @@ __global__ void __launch_bounds__(SB) bn_small_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
                                                           int training, float* __restrict__ gx, float* __restrict__ ggamma,
                                                           float* __restrict__ gbeta, int B, int C, int HW, int accumulate,
-                                                          const float* __restrict__ add) {
+                                                          const float* __restrict__ add, int G, int add_groups) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
-  const SmallIdx ix(B, C, HW, c);
-  const float r = invstd[c], mu = mean[c], a = gamma[c] * r, b = beta[c] - mu * a;
-  float gyh[SPER], xh[SPER];
-#pragma unroll
-  for (int i = 0; i < SPER; ++i) {
-    const float xv = ix.ok[i] ? x[ix.off[i]] : mu;
-    const float g = ix.ok[i] ? gz[ix.off[i]] : 0.f;
-    gyh[i] = bn_y(xv, a, b) >= 0.f ? g : g * slope;
-    xh[i] = (xv - mu) * r;
-  }
-  float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-  for (int i = 0; i < SPER; ++i) { a0 += gyh[i]; a1 += gyh[i] * xh[i]; }
   const double n = (double)B * HW;
-  const double sb = block_sum_d1024((double)a0, scratch), sg = block_sum_d1024((double)a1, scratch);
-  if (threadIdx.x == 0) {
-    gbeta[c] = (float)sb + (accumulate ? gbeta[c] : 0.f);
-    ggamma[c] = (float)sg + (accumulate ? ggamma[c] : 0.f);
-  }
-  if (gx == nullptr) return;
-  const float k1 = (float)(sb / n), k2 = (float)(sg / n);
+  double tb = 0.0, tg = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const SmallIdx ix(B, C, HW, c, (int64_t)g * B * C * HW);
+    const float r = invstd[g * C + c], mu = mean[g * C + c], a = gamma[c] * r, b = beta[c] - mu * a;
+    float gyh[SPER], xh[SPER];
 #pragma unroll
-  for (int i = 0; i < SPER; ++i)
-    if (ix.ok[i]) gx[ix.off[i]] = (training ? a * (gyh[i] - k1 - xh[i] * k2) : a * gyh[i]) + (add ? add[ix.off[i]] : 0.f);
+    for (int i = 0; i < SPER; ++i) {
+      const float xv = ix.ok[i] ? x[ix.off[i]] : mu;
+      const float gg = ix.ok[i] ? gz[ix.off[i]] : 0.f;
+      gyh[i] = bn_y(xv, a, b) >= 0.f ? gg : gg * slope;
+      xh[i] = (xv - mu) * r;
+    }
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPER; ++i) { a0 += gyh[i]; a1 += gyh[i] * xh[i]; }
+    const double sb = block_sum_d1024((double)a0, scratch), sg = block_sum_d1024((double)a1, scratch);
+    tb += sb; tg += sg;
+    if (gx != nullptr) {
+      const float k1 = (float)(sb / n), k2 = (float)(sg / n);
+      const bool use_add = add != nullptr && g < add_groups;
+#pragma unroll
+      for (int i = 0; i < SPER; ++i)
+        if (ix.ok[i]) gx[ix.off[i]] = (training ? a * (gyh[i] - k1 - xh[i] * k2) : a * gyh[i]) + (use_add ? add[ix.off[i]] : 0.f);
+    }
+  }
+  if (threadIdx.x == 0) {
+    gbeta[c] = (float)tb + (accumulate ? gbeta[c] : 0.f);
+    ggamma[c] = (float)tg + (accumulate ? ggamma[c] : 0.f);
+  }
 }
 
 __global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restrict__ v, const float* __restrict__ vgamma,
@@ -609,48 +664,72 @@ size_t tg_bn_workspace(int B, int C, int HW) {
   return (size_t)C * S * MAXK * sizeof(double) + (size_t)C * COEF * sizeof(float);
 }
 
-int tg_bn_train_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
-                      int64_t* num_batches_tracked, float momentum, float eps, float* workspace, int B, int C, int HW,
-                      int replicate, void* stream) {
+static int train_stats_groups(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                              int64_t* num_batches_tracked, float momentum, float eps, float* workspace, int G, int B, int C, int HW,
+                              int replicate, void* stream) {
   TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(workspace);
-  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW); TG_CHECK_POS(replicate);
+  TG_CHECK_POS(G); TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW); TG_CHECK_POS(replicate);
   if ((running_mean == nullptr) != (running_var == nullptr)) return TG_EINVAL;
   hipStream_t st = tg_stream(stream);
-  Parts p = split_ws(workspace, B, C, HW);
+  Parts p = split_ws(workspace, B, G * C, HW);
   RedStats red{x, C, HW, 0.f};
-  planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x));
+  planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x), G);
   stats_stage2<<<C, 64, 0, st>>>(p.partial, x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, B, C, HW,
-                                            planes::splits(B, C, HW), replicate);
+                                            planes::splits(B, G * C, HW), replicate, G);
   return tg_launch_status();
 }
 
-int tg_bn_train_fwd(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
-                    int64_t* num_batches_tracked, const float* gamma, const float* beta, float slope, float momentum, float eps,
-                    float* z, float* workspace, int B, int C, int HW, int replicate, void* stream) {
+int tg_bn_train_stats(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float momentum, float eps, float* workspace, int B, int C, int HW,
+                      int replicate, void* stream) {
+  return train_stats_groups(x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, workspace, 1, B, C, HW,
+                            replicate, stream);
+}
+
+static int act_fwd_groups(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                          float* z, int G, int B, int C, int HW, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta); TG_CHECK_PTR(z);
+  TG_CHECK_POS(G); TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  FwdBody body{x, z, mean, invstd, gamma, beta, slope};
+  planes::launch_map(body, G * B, C, HW, tg_stream(stream), tg_aligned16(x) && tg_aligned16(z), B);
+  return tg_launch_status();
+}
+
+int tg_bn_train_fwd_groups(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, const float* gamma, const float* beta, float slope, float momentum,
+                           float eps, float* z, float* workspace, int groups, int B, int C, int HW, int replicate, void* stream) {
   TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta); TG_CHECK_PTR(z);
   TG_CHECK_PTR(workspace);
-  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW); TG_CHECK_POS(replicate);
+  TG_CHECK_POS(groups); TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW); TG_CHECK_POS(replicate);
   if ((running_mean == nullptr) != (running_var == nullptr)) return TG_EINVAL;
+  const int G = groups;
   if (small_case(B, C, HW)) {
     bn_small_fwd_kernel<<<C, SB, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
-                                                            gamma, beta, slope, momentum, eps, z, B, C, HW, replicate);
+                                                            gamma, beta, slope, momentum, eps, z, B, C, HW, replicate, G);
     return tg_launch_status();
   }
   if (planes::big(HW) && tg_aligned16(x) && tg_aligned16(z)) {
     // two launches: the per-block partial sums, then the apply pass, whose blocks finish the reduction themselves
     hipStream_t st = tg_stream(stream);
-    Parts p = split_ws(workspace, B, C, HW);
+    Parts p = split_ws(workspace, B, G * C, HW);
     RedStats red{x, C, HW, 0.f};
-    planes::launch_reduce(red, p.partial, B, C, HW, st, true);
+    planes::launch_reduce(red, p.partial, B, C, HW, st, true, G);
     FwdStatsBody body{x, z, p.partial, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta,
-                      slope, momentum, eps, B, HW, planes::splits(B, C, HW), replicate, 0.f, 0.f};
-    planes::launch_map_begin(body, B, C, HW, st);
+                      slope, momentum, eps, B, HW, planes::splits(B, G * C, HW), replicate, C, G, 0.f, 0.f};
+    planes::launch_map_begin(body, B, C, HW, st, G);
     return tg_launch_status();
   }
-  if (int rc = tg_bn_train_stats(x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, workspace, B, C,
-                                 HW, replicate, stream))
+  if (int rc = train_stats_groups(x, mean, invstd, running_mean, running_var, num_batches_tracked, momentum, eps, workspace, G, B, C,
+                                  HW, replicate, stream))
     return rc;
-  return tg_bn_act_fwd(x, mean, invstd, gamma, beta, slope, z, B, C, HW, stream);
+  return act_fwd_groups(x, mean, invstd, gamma, beta, slope, z, G, B, C, HW, stream);
+}
+
+int tg_bn_train_fwd(const float* x, float* mean, float* invstd, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, const float* gamma, const float* beta, float slope, float momentum, float eps,
+                    float* z, float* workspace, int B, int C, int HW, int replicate, void* stream) {
+  return tg_bn_train_fwd_groups(x, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta, slope, momentum, eps,
+                                z, workspace, 1, B, C, HW, replicate, stream);
 }
 
 int tg_bn_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, float eps, int C,
@@ -663,41 +742,47 @@ int tg_bn_eval_stats(const float* running_mean, const float* running_var, float*
 
 int tg_bn_act_fwd(const float* x, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                   float* z, int B, int C, int HW, void* stream) {
-  TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta); TG_CHECK_PTR(z);
-  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
-  FwdBody body{x, z, mean, invstd, gamma, beta, slope};
-  planes::launch_map(body, B, C, HW, tg_stream(stream), tg_aligned16(x) && tg_aligned16(z));
+  return act_fwd_groups(x, mean, invstd, gamma, beta, slope, z, 1, B, C, HW, stream);
+}
+
+int tg_bn_act_bwd_groups(const float* gz, const float* x, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, float slope, int training, float* gx, float* ggamma, float* gbeta, float* workspace,
+                         int groups, int B, int C, int HW, int accumulate, const float* gx_add, int add_groups, void* stream) {
+  TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta);
+  TG_CHECK_PTR(ggamma); TG_CHECK_PTR(gbeta); TG_CHECK_PTR(workspace);
+  TG_CHECK_POS(groups); TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
+  if (gx_add != nullptr && (gx == nullptr || add_groups < 1 || add_groups > groups)) return TG_EINVAL;
+  const int G = groups;
+  hipStream_t st = tg_stream(stream);
+  if (small_case(B, C, HW)) {
+    bn_small_bwd_kernel<<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
+                                             accumulate, gx_add, G, add_groups);
+    return tg_launch_status();
+  }
+  Parts p = split_ws(workspace, B, G * C, HW);
+  const int S = planes::splits(B, G * C, HW);
+  const int add_vc_end = add_groups * C;
+  RedBwd red{gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
+  planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz), G);
+  if (gx != nullptr && planes::big(HW) && tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx) && (!gx_add || tg_aligned16(gx_add))) {
+    BwdSumsBody body{gz, x, gx, p.partial, mean, invstd, gamma, beta, ggamma, gbeta, slope, training, accumulate,
+                     B, HW, S, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, gx_add, C, G, add_vc_end, false};
+    planes::launch_map_begin(body, B, C, HW, st, G);
+    return tg_launch_status();
+  }
+  bwd_stage2<<<C, 64, 0, st>>>(p.partial, ggamma, gbeta, p.coef, B, C, HW, S, accumulate, G);
+  if (gx != nullptr) {
+    BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, training, gx_add, add_vc_end};
+    planes::launch_map(body, G * B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx) && (!gx_add || tg_aligned16(gx_add)), B);
+  }
   return tg_launch_status();
 }
 
 int tg_bn_act_bwd(const float* gz, const float* x, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, float slope, int training, float* gx, float* ggamma, float* gbeta, float* workspace,
                   int B, int C, int HW, int accumulate, const float* gx_add, void* stream) {
-  TG_CHECK_PTR(gz); TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(invstd); TG_CHECK_PTR(gamma); TG_CHECK_PTR(beta);
-  TG_CHECK_PTR(ggamma); TG_CHECK_PTR(gbeta); TG_CHECK_PTR(workspace);
-  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
-  hipStream_t st = tg_stream(stream);
-  if (small_case(B, C, HW)) {
-    bn_small_bwd_kernel<<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
-                                             accumulate, gx_add);
-    return tg_launch_status();
-  }
-  Parts p = split_ws(workspace, B, C, HW);
-  RedBwd red{gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
-  planes::launch_reduce(red, p.partial, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz));
-  if (gx_add != nullptr && gx == nullptr) return TG_EINVAL;
-  if (gx != nullptr && planes::big(HW) && tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx) && (!gx_add || tg_aligned16(gx_add))) {
-    BwdSumsBody body{gz, x, gx, p.partial, mean, invstd, gamma, beta, ggamma, gbeta, slope, training, accumulate,
-                     B, HW, planes::splits(B, C, HW), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, gx_add};
-    planes::launch_map_begin(body, B, C, HW, st);
-    return tg_launch_status();
-  }
-  bwd_stage2<<<C, 64, 0, st>>>(p.partial, ggamma, gbeta, p.coef, B, C, HW, planes::splits(B, C, HW), accumulate);
-  if (gx != nullptr) {
-    BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, training, gx_add};
-    planes::launch_map(body, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx) && (!gx_add || tg_aligned16(gx_add)));
-  }
-  return tg_launch_status();
+  return tg_bn_act_bwd_groups(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, workspace, 1, B, C, HW,
+                              accumulate, gx_add, 1, stream);
 }
 
 int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, const float* gz, const float* x,
@@ -772,7 +857,7 @@ int tg_bn_sync_bwd_finish(const float* gz, const float* x, const float* mean, co
   Parts p = split_ws(workspace, B, C, HW);
   sync_bwd_finish<<<chan_grid(C), 64, 0, st>>>(local_sums, global_sums, (double)count_global, ggamma, gbeta, p.coef, C, accumulate);
   if (gx != nullptr) {
-    BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, 1, gx_add};
+    BwdBody body{gz, x, gx, mean, invstd, gamma, beta, p.coef, slope, 1, gx_add, C};
     planes::launch_map(body, B, C, HW, st, tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(gx));
   }
   return tg_launch_status();

@@ -76,6 +76,28 @@ __global__ void __launch_bounds__(EW_BLOCK) ew_add4(const float* __restrict__ a,
   }
 }
 
+// dst (B, Cd, HW) <- src (B, Cs, HW): channels [0, min(Cs, Cd)) copied, channels >= Cs filled.  One thread per float4 (or
+// float when HW % 4) of dst; HBM-bound, one pass.
+template <int VEC>
+__global__ void __launch_bounds__(EW_BLOCK) copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t planes_dst,
+                                                                 int Cs, int Cd, int HW, float fill) {
+  const int per = HW / VEC;
+  const int64_t total = planes_dst * per;
+  for (int64_t i = blockIdx.x * (int64_t)EW_BLOCK + threadIdx.x; i < total; i += gridDim.x * (int64_t)EW_BLOCK) {
+    const int64_t plane = i / per;
+    const int p = (int)(i - plane * per) * VEC;
+    const int64_t b = plane / Cd;
+    const int c = (int)(plane - b * Cd);
+    if (VEC == 4) {
+      float4 v = make_float4(fill, fill, fill, fill);
+      if (c < Cs) v = *reinterpret_cast<const float4*>(src + (b * Cs + c) * (int64_t)HW + p);
+      *reinterpret_cast<float4*>(dst + plane * (int64_t)HW + p) = v;
+    } else {
+      dst[plane * (int64_t)HW + p] = c < Cs ? src[(b * Cs + c) * (int64_t)HW + p] : fill;
+    }
+  }
+}
+
 struct OpScale { float alpha; __device__ float operator()(float x) const { return x * alpha; } };
 struct OpScaleDev {
   const float* s; float alpha;
@@ -283,6 +305,16 @@ int tg_elu_fwd(const float* x, float alpha, float scale, float* y, int64_t n, vo
 int tg_elu_bwd(const float* g, const float* x, float alpha, float scale, int order, float* out, int64_t n, void* stream) {
   if (order != 1 && order != 2) return TG_EINVAL;
   return launch_binary(g, x, out, n, stream, OpEluBwd{alpha * scale, scale, order});
+}
+int tg_copy_channels(const float* src, float* dst, int B, int Cs, int Cd, int HW, float fill, void* stream) {
+  TG_CHECK_PTR(src); TG_CHECK_PTR(dst);
+  TG_CHECK_POS(B); TG_CHECK_POS(Cs); TG_CHECK_POS(Cd); TG_CHECK_POS(HW);
+  const int64_t planes_dst = (int64_t)B * Cd;
+  if (HW % 4 == 0 && tg_aligned16(src) && tg_aligned16(dst))
+    copy_channels_kernel<4><<<tg_ew_grid(planes_dst * (HW / 4), EW_BLOCK), EW_BLOCK, 0, tg_stream(stream)>>>(src, dst, planes_dst, Cs, Cd, HW, fill);
+  else
+    copy_channels_kernel<1><<<tg_ew_grid(planes_dst * HW, EW_BLOCK), EW_BLOCK, 0, tg_stream(stream)>>>(src, dst, planes_dst, Cs, Cd, HW, fill);
+  return tg_launch_status();
 }
 int tg_fill(float* x, float value, int64_t n, void* stream) { return launch_unary<OpFill, false>(nullptr, x, n, stream, OpFill{value}); }
 

@@ -20,7 +20,7 @@ static inline int row_grid(int rows) {
 struct RedChan {
   static constexpr int K = 1;
   const float* x;
-  __device__ void init(int) {}
+  __device__ void init(const planes::Chan&) {}
   using V = float4;
   __device__ V ld4(int64_t off) const { return *reinterpret_cast<const float4*>(x + off); }
   __device__ void acc(const V& v, float* a) { a[0] += (v.x + v.y) + (v.z + v.w); }
@@ -35,11 +35,11 @@ __global__ void chan_stage2(const double* __restrict__ partial, float* __restric
 
 struct BcastBody {
   const float* v; float* out;
-  __device__ void vec4(int c, int64_t off) const {
-    const float s = v[c];
+  __device__ void vec4(const planes::Chan& ch, int64_t off) const {
+    const float s = v[ch.c];
     *reinterpret_cast<float4*>(out + off) = make_float4(s, s, s, s);
   }
-  __device__ void one(int c, int64_t off) const { out[off] = v[c]; }
+  __device__ void one(const planes::Chan& ch, int64_t off) const { out[off] = v[ch.c]; }
 };
 
 // ------------------------------------------------------------------ row sum / bcast / repeat

@@ -16,10 +16,54 @@ Linear ops come as transpose pairs (each is the other's backward):
 import contextlib
 
 import torch
-from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import backend as _be
+
+
+class Function(torch.autograd.Function):
+    """``torch.autograd.Function`` that never works on gradients nobody sent.
+
+    By default autograd materialises a missing output gradient as zeros and runs ``backward`` on it.  With the real and
+    the fake batch of the discriminator in one graph (``Pair``), the R1 penalty's ``autograd.grad(p_real.sum(), real)``
+    reaches every node of the FAKE half that feeds a shared node with an undefined gradient -- zeros would then be pushed
+    through its kernels and arrive at the shared nodes looking like a gradient for both halves.  Every Function of this
+    module therefore opts out of materialisation: ``backward`` is skipped (all-None result) when no output received a
+    gradient, and a partially missing set is zero-filled only for the Functions that do not handle None themselves
+    (``handles_none_grads``)."""
+    handles_none_grads = False
+
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        fwd, bwd = cls.__dict__.get('forward'), cls.__dict__.get('backward')
+        if isinstance(fwd, staticmethod) and isinstance(bwd, staticmethod):
+            cls.forward = staticmethod(_wrap_forward(cls, fwd.__func__))
+            cls.backward = staticmethod(_wrap_backward(cls, bwd.__func__))
+
+
+def _wrap_forward(cls, fwd):
+    def forward(ctx, *args):
+        out = fwd(ctx, *args)
+        ctx.set_materialize_grads(False)
+        ctx._n_inputs = len(args)
+        if not cls.handles_none_grads:
+            outs = out if isinstance(out, tuple) else (out,)
+            ctx._out_meta = [(tuple(o.shape), o.dtype, o.device) if torch.is_tensor(o) else None for o in outs]
+        return out
+    forward.__doc__, forward.__name__ = fwd.__doc__, fwd.__name__
+    return forward
+
+
+def _wrap_backward(cls, bwd):
+    def backward(ctx, *grads):
+        if all(g is None for g in grads):
+            return (None,) * ctx._n_inputs
+        if not cls.handles_none_grads and any(g is None for g in grads):
+            grads = tuple(torch.zeros(m[0], dtype=m[1], device=m[2]) if (g is None and m is not None) else g
+                          for g, m in zip(grads, ctx._out_meta))
+        return bwd(ctx, *grads)
+    backward.__doc__, backward.__name__ = bwd.__doc__, bwd.__name__
+    return backward
 
 
 def K():
@@ -91,6 +135,256 @@ def input_grads_only():
 
 def _param_grads_wanted():
     return not _InputGradsOnly.active
+
+
+# =========================================================================== real | fake pairs
+class Pair:
+    """The real and the fake batch of a discriminator step travelling through the network as ONE tensor of 2B images.
+
+    The reference evaluates D twice with the same weights (trainers/cnn.py:122-123, iqn.py:118-119).  Convolutions,
+    resampling, attention and the heads are per-image maps, so both evaluations can share every kernel launch -- twice the
+    grid on the small-plane layers that underfill the chip, half the launches on the launch-bound ones; BatchNorm keeps
+    per-half statistics (tg_bn_*_groups).  For autograd the halves stay SEPARATE tensors (``r``, ``f``: views of one
+    (2B, ...) buffer): the R1 penalty differentiates the real half alone (its first-order pass and the second-order sweep
+    run on B images exactly as before), while the final backward, which reaches a layer with both halves' gradients, runs
+    each backward kernel once on 2B.  See ``_Paired``."""
+    __slots__ = ('r', 'f')
+
+    def __init__(self, r, f):
+        if r.shape != f.shape or r.dtype != f.dtype or r.device != f.device:
+            raise ValueError(f'Pair: halves differ ({tuple(r.shape)} {r.dtype} vs {tuple(f.shape)} {f.dtype})')
+        self.r, self.f = r, f
+
+    @property
+    def shape(self):
+        return torch.Size((2 * self.r.shape[0],) + tuple(self.r.shape[1:]))
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    def dim(self):
+        return self.r.dim()
+
+    def __len__(self):
+        return 2 * self.r.shape[0]
+
+    @property
+    def requires_grad(self):
+        return self.r.requires_grad or self.f.requires_grad
+
+    @property
+    def device(self):
+        return self.r.device
+
+    def view(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        if shape[0] != -1:
+            if shape[0] != 2 * self.r.shape[0]:
+                raise ValueError('Pair.view: the leading (image) dimension must stay')
+            shape = (self.r.shape[0],) + tuple(shape[1:])
+        return Pair(self.r.view(*shape), self.f.view(*shape))
+
+
+def _join(r, f):
+    """One (2B, ...) tensor over both halves: an alias when they lie back to back in one storage (what every paired op
+    returns), a copy otherwise (the network input; a gradient autograd had to sum out of place)."""
+    if (r.numel() and r.is_contiguous() and f.is_contiguous()
+            and r.untyped_storage().data_ptr() == f.untyped_storage().data_ptr()
+            and f.storage_offset() == r.storage_offset() + r.numel()):
+        return r.as_strided((2 * r.shape[0],) + tuple(r.shape[1:]), r.stride(), r.storage_offset())
+    out = r.new_empty((2 * r.shape[0],) + tuple(r.shape[1:]))
+    out[:r.shape[0]].copy_(r)
+    out[r.shape[0]:].copy_(f)
+    return out
+
+
+class _PairCtx:
+    """What a Function's ``forward`` / ``backward`` see in place of the autograd ctx when ``_Paired`` runs them."""
+
+    def __init__(self):
+        self.saved_tensors = ()
+        self.materialize = True
+        self.needs_input_grad = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def set_materialize_grads(self, flag):
+        self.materialize = bool(flag)
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+# Function -> (forward arguments: 'b' a batch tensor, '-' anything else;
+#              saved tensors:     'h' halve along dim 0 for the real-half view, '-' keep;
+#              outputs:           'b' batch tensor, '-' other; '*' = all batch)
+PAIR_SPECS = {}
+
+
+class _Paired(Function):
+    """Run Function ``F`` on the two halves of a ``Pair`` as one batch.
+
+    forward : the halves are joined (an alias, see ``_join``), ``F.forward`` runs ONCE on 2B images, the outputs are handed
+              back as two views.  Autograd sees one node with inputs (.., x_r, x_f, ..) and outputs (y_r, y_f).
+    backward: gradients for BOTH halves (the final backward of the D phase) -> joined, ``F.backward`` runs once on 2B;
+              a gradient for the REAL half only (the R1 penalty's ``autograd.grad(p_real.sum(), real, create_graph=True)``)
+              -> ``F.backward`` runs on the real-half views of the saved tensors, building exactly the graph the unpaired
+              real pass would build (B images; its second-order sweep is untouched).
+    ``F``'s own forward / backward are reused unchanged through a stand-in ctx (``_PairCtx``)."""
+    handles_none_grads = True
+
+    @staticmethod
+    def forward(ctx, F, *args):
+        layout, _, out_spec = PAIR_SPECS[F]
+        fargs, pos, reals, joined = [], 0, [], {}
+        for kind in layout:
+            if kind == 'b':
+                r, f = args[pos], args[pos + 1]
+                pos += 2
+                if r is None:
+                    fargs.append(None)
+                else:
+                    both = _join(r.contiguous(), f.contiguous())
+                    fargs.append(both)
+                    joined[id(both)] = len(reals)
+                    reals.append(r)
+            else:
+                fargs.append(args[pos])
+                pos += 1
+        if hasattr(F, 'pair_full'):
+            fargs = F.pair_full(fargs)
+        rec = _PairCtx()
+        out = F.forward(rec, *fargs)
+        outs = out if isinstance(out, tuple) else (out,)
+        kinds = out_spec if out_spec != '*' else 'b' * len(outs)
+        # A saved tensor that IS a joined batch input is remembered as such: the real-half pass of ``backward`` must hand
+        # ``F.backward`` the ORIGINAL real input (a saved input is re-attached to the graph when unpacked; the joined alias
+        # made in here has no history), or the R1 penalty's second derivative through that input would be lost.
+        ctx.from_input = [None if t is None else joined.get(id(t)) for t in rec.saved_tensors]
+        ctx.save_for_backward(*rec.saved_tensors, *reals)
+        ctx.F, ctx.kinds, ctx.materialize = F, kinds, rec.materialize
+        ctx.attrs = {k: v for k, v in vars(rec).items() if k not in ('saved_tensors', 'materialize', 'needs_input_grad')}
+        ctx.set_materialize_grads(False)
+        flat = []
+        for kind, o in zip(kinds, outs):
+            if kind == 'b':
+                n = o.shape[0] // 2
+                flat += [o[:n], o[n:]]
+            else:
+                flat.append(o)
+        ctx.out_meta = [(tuple(o.shape), o.dtype) for o in flat]
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        F, kinds = ctx.F, ctx.kinds
+        layout, saved_spec, _ = PAIR_SPECS[F]
+        n_in = sum(2 if k == 'b' else 1 for k in layout)
+        if all(g is None for g in gouts):
+            return (None,) * (1 + n_in)
+        groups, pos = [], 0                      # per output of F: (kind, real grad, fake grad) / (kind, grad, None)
+        for kind in kinds:
+            if kind == 'b':
+                groups.append((kind, gouts[pos], gouts[pos + 1], pos))
+                pos += 2
+            else:
+                groups.append((kind, gouts[pos], None, pos))
+                pos += 1
+        half = all(gf is None for kind, _, gf, _ in groups if kind == 'b') and any(kind == 'b' for kind, *_ in groups)
+        need = ctx.needs_input_grad
+        sub = _PairCtx()
+        sub.__dict__.update(ctx.attrs)
+        sub_need, pos = [], 1
+        for kind in layout:
+            if kind == 'b':
+                sub_need.append(need[pos] if half else (need[pos] or need[pos + 1]))
+                pos += 2
+            else:
+                sub_need.append(need[pos])
+                pos += 1
+        sub.needs_input_grad = tuple(sub_need)
+        saved, reals = ctx.saved_tensors[:len(ctx.from_input)], ctx.saved_tensors[len(ctx.from_input):]
+        device = next(g for g in gouts if g is not None).device
+
+        def zeros(at):
+            shape, dtype = ctx.out_meta[at]
+            return torch.zeros(shape, dtype=dtype, device=device)
+
+        gin = []
+        if half:
+            sub.saved_tensors = tuple(reals[j] if j is not None else (t[:t.shape[0] // 2] if (k == 'h' and t is not None) else t)
+                                      for k, t, j in zip(saved_spec, saved, ctx.from_input))
+            if hasattr(F, 'pair_half'):
+                F.pair_half(sub)
+            for kind, g, _, at in groups:
+                gin.append(zeros(at) if (g is None and ctx.materialize) else g)
+        else:
+            sub.saved_tensors = saved
+            for kind, g, gf, at in groups:
+                if kind != 'b':
+                    gin.append(zeros(at) if (g is None and ctx.materialize) else g)
+                elif g is None and gf is None:
+                    gin.append(_join(zeros(at), zeros(at + 1)) if ctx.materialize else None)
+                else:
+                    g = zeros(at) if g is None else g.contiguous()
+                    gf = zeros(at + 1) if gf is None else gf.contiguous()
+                    gin.append(_join(g, gf))
+        res = F.backward(sub, *gin)
+        res = res if isinstance(res, tuple) else (res,)
+        res = tuple(res) + (None,) * (len(layout) - len(res))
+        out = [None]
+        for kind, g in zip(layout, res):
+            if kind != 'b':
+                out.append(g)
+            elif g is None:
+                out += [None, None]
+            elif half:
+                out += [g, None]
+            else:
+                n = g.shape[0] // 2
+                out += [g[:n], g[n:]]
+        return tuple(out)
+
+
+def pair_apply(F, *fargs):
+    """``F.apply`` for arguments that contain ``Pair``s (every batch argument a Pair or None) -> Pair(s) for batch outputs."""
+    layout, _, out_spec = PAIR_SPECS[F]
+    if len(fargs) != len(layout):
+        raise TypeError(f'{F.__name__}: {len(layout)} arguments expected for the paired form, got {len(fargs)}')
+    flat = []
+    for kind, a in zip(layout, fargs):
+        if kind != 'b':
+            flat.append(a)
+        elif a is None:
+            flat += [None, None]
+        elif isinstance(a, Pair):
+            flat += [a.r, a.f]
+        else:
+            raise TypeError(f'{F.__name__}: a batch argument of the paired form must be a Pair (or None)')
+    outs = _Paired.apply(F, *flat)
+    kinds = out_spec if out_spec != '*' else 'b' * (len(outs) // 2)
+    res, pos = [], 0
+    for kind in kinds:
+        if kind == 'b':
+            res.append(Pair(outs[pos], outs[pos + 1]))
+            pos += 2
+        else:
+            res.append(outs[pos])
+            pos += 1
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def _is_pair(x):
+    return isinstance(x, Pair)
+
+
+def per_half(fn, x, *args, **kw):
+    """Fallback for an op without a paired form: run it on each half (real first -- RNG / running-statistics order)."""
+    r = fn(x.r, *args, **kw)
+    f = fn(x.f, *args, **kw)
+    return Pair(r, f)
 
 
 # =========================================================================== conv
@@ -288,7 +582,12 @@ class _ChannelBcast(Function):
 def conv2d(x, weight, bias=None, residual=None, residual_up=False):
     """3x3 (pad 1) or 1x1 (pad 0) stride-1 convolution, NCHW fp32; optional fused ``+ residual`` (``residual_up``: a half-resolution
     residual, added nearest-neighbour upsampled by the 3x3 kernel's epilogue)."""
+    if _is_pair(x):
+        return pair_apply(_ConvFwd, x, weight, bias, residual, residual_up)
     return _ConvFwd.apply(x, weight, bias, residual, residual_up)
+
+
+PAIR_SPECS[_ConvFwd] = ('b--b-', 'h--', 'b')
 
 
 # =========================================================================== GEMM
@@ -516,7 +815,12 @@ def pool_conv3x3_supported(x, weight):
 
 def pool_conv3x3(x, weight, bias=None, residual=None):
     """F.avg_pool2d(F.conv2d(x, weight, bias, padding=1), 2) [+ residual]"""
+    if _is_pair(x):
+        return pair_apply(_PoolConv, x, weight, bias, residual)
     return _PoolConv.apply(x, weight, bias, residual)
+
+
+PAIR_SPECS[_PoolConv] = ('b--b', 'h--', 'b')
 
 
 class _Gemm(Function):
@@ -619,7 +923,12 @@ class _Linear(Function):
 
 
 def linear(x, weight, bias=None):
+    if _is_pair(x):
+        return pair_apply(_Linear, x, weight, bias)
     return _Linear.apply(x, weight, bias)
+
+
+PAIR_SPECS[_Linear] = ('b--', 'h--', 'b')
 
 
 # =========================================================================== BatchNorm (+LeakyReLU)
@@ -656,13 +965,22 @@ class _BNCell:
 class _BNAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, num_batches_tracked=None,
-                replicate=1, sync=None):
+                replicate=1, sync=None, groups=1):
         x = x.contiguous()
-        B, C = x.shape[0], x.shape[1]
+        B, C = x.shape[0] // groups, x.shape[1]
         hw = x[0, 0].numel()
-        mean, invstd = x.new_empty(C), x.new_empty(C)
+        mean, invstd = x.new_empty(groups * C), x.new_empty(groups * C)
         z = torch.empty_like(x)
-        if training and sync is not None and sync.world > 1:
+        if groups > 1:
+            # the real and the fake batch in one tensor (``Pair``): statistics per half, running statistics updated
+            # real-then-fake, num_batches_tracked += 2 -- what the reference's two forwards leave behind
+            if not training or (sync is not None and sync.world > 1) or x.shape[0] != groups * B:
+                raise RuntimeError('grouped BatchNorm: training mode, local statistics, equal groups only')
+            sync = None
+            ws = _ws(x, K().bn_workspace(B, groups * C, hw))
+            K().bn_train_fwd_groups(x, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta,
+                                    float(slope), float(momentum), float(eps), z, ws, groups, B, C, hw, int(replicate))
+        elif training and sync is not None and sync.world > 1:
             ws = _ws(x, K().bn_workspace(B, C, hw))
             sums = _sums(x, C, 3)
             K().bn_sync_stats_local(x, sums, ws, B, C, hw)
@@ -680,15 +998,24 @@ class _BNAct(Function):
             K().bn_eval_stats(running_mean, running_var, mean, invstd, float(eps), C)
             K().bn_act_fwd(x, mean, invstd, gamma, beta, float(slope), z, B, C, hw)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
-        ctx.training, ctx.slope, ctx.sync = bool(training), float(slope), sync
+        ctx.training, ctx.slope, ctx.sync, ctx.groups = bool(training), float(slope), sync, groups
         ctx.cell = _BNCell()
         return z
+
+    @staticmethod
+    def pair_full(fargs):
+        fargs[12] = 2
+        return fargs
+
+    @staticmethod
+    def pair_half(sub):
+        sub.groups = 1                  # the real-half view: one group, its own statistics (the first C entries)
 
     @staticmethod
     def backward(ctx, gz):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
         sink_g, sink_b = _grad_sink(gamma), _grad_sink(beta)
-        nones = (None,) * 9
+        nones = (None,) * 10
         if sink_g is not None and sink_b is not None:
             # plain backward: ggamma / gbeta accumulate straight into the flat bucket
             gz = gz.contiguous()
@@ -697,19 +1024,25 @@ class _BNAct(Function):
             extra, cell.pending, cell.consumed = cell.pending, None, True
             if gx is None:
                 extra = None
-            _bn_bwd_into(gz, x, mean, invstd, gamma, beta, ctx.slope, ctx.training, gx, sink_g, sink_b, 1, ctx.sync, extra)
+            _bn_bwd_into(gz, x, mean, invstd, gamma, beta, ctx.slope, ctx.training, gx, sink_g, sink_b, 1, ctx.sync, extra, ctx.groups)
             return (gx, None, None) + nones
         # (a second-order gradient is only ever parked inside grads_into_buckets(), i.e. for the branch above)
         assert ctx.cell.pending is None, 'BatchNorm: a parked second-order input gradient would be dropped'
         gx, gg, gb = _BNActBwd.apply(gz, x, gamma, beta, mean, invstd, ctx.slope, ctx.training,
-                                     ctx.needs_input_grad[0], ctx.sync, ctx.cell)
+                                     ctx.needs_input_grad[0], ctx.sync, ctx.cell, ctx.groups)
         return (gx, gg, gb) + nones
 
 
-def _bn_bwd_into(gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, accumulate, sync, gx_add=None):
-    B, C = x.shape[0], x.shape[1]
+def _bn_bwd_into(gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, accumulate, sync, gx_add=None, groups=1):
+    B, C = x.shape[0] // groups, x.shape[1]
     hw = x[0, 0].numel()
-    ws = _ws(x, K().bn_workspace(B, C, hw))
+    ws = _ws(x, K().bn_workspace(B, groups * C, hw))
+    if groups > 1:
+        # gx_add: the R1 second-order gradient, which exists for the leading (real) group(s) only
+        add_groups = 1 if gx_add is None else gx_add.shape[0] // B
+        K().bn_act_bwd_groups(gz, x, mean, invstd, gamma, beta, slope, int(training), gx, gg, gb, ws, groups, B, C, hw, accumulate,
+                              gx_add, add_groups)
+        return
     if sync is None:
         K().bn_act_bwd(gz, x, mean, invstd, gamma, beta, slope, int(training), gx, gg, gb, ws, B, C, hw, accumulate, gx_add)
         return
@@ -721,15 +1054,17 @@ def _bn_bwd_into(gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, 
 
 
 class _BNActBwd(Function):
+    handles_none_grads = True
+
     @staticmethod
-    def forward(ctx, gz, x, gamma, beta, mean, invstd, slope, training, need_gx=True, sync=None, cell=None):
+    def forward(ctx, gz, x, gamma, beta, mean, invstd, slope, training, need_gx=True, sync=None, cell=None, groups=1):
         gz = gz.contiguous()
         C = x.shape[1]
         gx = torch.empty_like(x) if need_gx else None
         gg, gb = x.new_empty(C), x.new_empty(C)
-        _bn_bwd_into(gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, 0, sync)
+        _bn_bwd_into(gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, 0, sync, None, groups)
         ctx.save_for_backward(gz, x, gamma, beta, mean, invstd)
-        ctx.slope, ctx.training, ctx.sync, ctx.cell = slope, training, sync, cell
+        ctx.slope, ctx.training, ctx.sync, ctx.cell, ctx.groups = slope, training, sync, cell, groups
         ctx.set_materialize_grads(False)        # the R1 pass never differentiates ggamma / gbeta: no zero fills for them
         return gx, gg, gb
 
@@ -738,6 +1073,8 @@ class _BNActBwd(Function):
     def backward(ctx, v, vg, vb):
         if not ctx.training:
             raise NotImplementedError('double backward through eval-mode BatchNorm is not implemented')
+        if ctx.groups != 1:
+            raise NotImplementedError('double backward through grouped BatchNorm (the R1 pass runs on the real half alone)')
         gz, x, gamma, beta, mean, invstd = ctx.saved_tensors
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
@@ -749,7 +1086,7 @@ class _BNActBwd(Function):
         if v is None:
             v = torch.zeros_like(x)
         v = v.contiguous()
-        nones = (None,) * 8
+        nones = (None,) * 9
         cell = ctx.cell
 
         def park(a_x):
@@ -779,8 +1116,17 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum
     stats kernel also bumps ``num_batches_tracked`` (int64 device scalar) when given.  ``replicate``: ``x`` stands
     for a tensor holding every element that many times (see tg_bn_train_stats); only running_var depends on it.
     ``sync``: a ``SyncGroup`` -- batch statistics and backward sums over all ranks' shards (SyncBN)."""
-    return _BNAct.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, slope,
+    if _is_pair(x):
+        if training and (sync is None or sync.world <= 1):
+            return pair_apply(_BNAct, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope,
+                              num_batches_tracked, replicate, None, 1)
+        return per_half(batch_norm_act, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope,
                         num_batches_tracked, replicate, sync)
+    return _BNAct.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, slope,
+                        num_batches_tracked, replicate, sync, 1)
+
+
+PAIR_SPECS[_BNAct] = ('b------------', 'h--hh', 'b')
 
 
 # =========================================================================== resampling
@@ -827,7 +1173,12 @@ def upsample_nearest2x(x):
 
 def avg_pool2(x, residual=None):
     """nn.AvgPool2d(2) [+ residual]"""
+    if _is_pair(x):
+        return pair_apply(_Pool2, x, 0.25, residual)
     return _Pool2.apply(x, 0.25, residual)
+
+
+PAIR_SPECS[_Pool2] = ('b-b', '', 'b')
 
 
 class _BilinearHalf(Function):
@@ -868,6 +1219,7 @@ class _ForkBilinearHalf(Function):
     """x -> (bilinear_half(x), x): the two uses of a discriminator block's input (shortcut and main path) as ONE graph
     node, so that its backward sees both incoming gradients and can add them inside the transpose kernel instead of
     leaving a separate full-resolution add to the autograd engine."""
+    handles_none_grads = True
 
     @staticmethod
     def forward(ctx, x):
@@ -889,6 +1241,7 @@ class _ForkBilinearHalf(Function):
 class _ForkUp2x(Function):
     """x -> (up2x(x), up2x(x)) (one tensor, two graph edges): the generator block's upsampled input feeds the shortcut
     and the main path; backward pools both incoming gradients without first adding them at the high resolution."""
+    handles_none_grads = True
 
     @staticmethod
     def forward(ctx, x):
@@ -909,7 +1262,12 @@ class _ForkUp2x(Function):
 
 def fork_bilinear_half(x):
     """-> (F.interpolate(x, scale_factor=0.5, mode='bilinear', align_corners=True), x)"""
+    if _is_pair(x):
+        return pair_apply(_ForkBilinearHalf, x)
     return _ForkBilinearHalf.apply(x)
+
+
+PAIR_SPECS[_ForkBilinearHalf] = ('b', '', 'bb')
 
 
 def fork_upsample_nearest2x(x):
@@ -919,7 +1277,12 @@ def fork_upsample_nearest2x(x):
 
 def bilinear_half(x):
     """F.interpolate(x, scale_factor=0.5, mode='bilinear', align_corners=True)"""
+    if _is_pair(x):
+        return pair_apply(_BilinearHalf, x)
     return _BilinearHalf.apply(x)
+
+
+PAIR_SPECS[_BilinearHalf] = ('b', '', 'b')
 
 
 class _MaxPool2(Function):
@@ -975,7 +1338,40 @@ class _MaxPoolGather(Function):
 
 
 def max_pool2(x):
+    if _is_pair(x):
+        return pair_apply(_MaxPool2, x)
     return _MaxPool2.apply(x)
+
+
+PAIR_SPECS[_MaxPool2] = ('b', 'h', 'b')
+
+
+class _CopyChannels(Function):
+    """x (B, C, H, W) -> (B, C2, H, W): channels [0, min(C, C2)) copied, channels beyond C filled with ``fill``.
+    C2 > C appends constant channels (the all-ones channel that carries the from-RGB bias into the composed first
+    convolution of the discriminator), C2 < C drops trailing ones; each is the other's transpose (with fill 0)."""
+
+    @staticmethod
+    def forward(ctx, x, channels, fill):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = x.new_empty(B, channels, H, W)
+        K().copy_channels(x, out, B, C, channels, H * W, float(fill))
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _CopyChannels.apply(g, ctx.C, 0.0), None, None
+
+
+def copy_channels(x, channels, fill=0.0):
+    if _is_pair(x):
+        return pair_apply(_CopyChannels, x, channels, fill)
+    return _CopyChannels.apply(x, channels, fill)
+
+
+PAIR_SPECS[_CopyChannels] = ('b--', '', 'b')
 
 
 # =========================================================================== row ops
@@ -1019,7 +1415,12 @@ class _RowBcast(Function):
 
 def sum_hw(x):
     """torch.sum(x, [2, 3])"""
+    if _is_pair(x):
+        return pair_apply(_RowSum, x, 2, 1.0)
     return _RowSum.apply(x, 2, 1.0)
+
+
+PAIR_SPECS[_RowSum] = ('b--', '', 'b')          # (only for reductions that keep the image dimension)
 
 
 class _RepeatRows(Function):
@@ -1077,7 +1478,12 @@ class _Add(Function):
 
 
 def add(a, b):
+    if _is_pair(a):
+        return pair_apply(_Add, a, b)
     return _Add.apply(a, b)
+
+
+PAIR_SPECS[_Add] = ('bb', '', 'b')
 
 
 class _SumN(Function):
@@ -1102,6 +1508,7 @@ class _ForkN(Function):
     """x -> n aliases of x, one graph node: its backward sees all n incoming gradients at once and adds them in ONE kernel
     (tg_add4) instead of the autograd engine's n - 1 separate adds.  For a tensor with several consumers inside a block
     (SelfAttention2d: theta, phi, g and the residual all read x)."""
+    handles_none_grads = True
 
     @staticmethod
     def forward(ctx, x, n):
@@ -1120,7 +1527,12 @@ class _ForkN(Function):
 
 def fork(x, n):
     """-> n tensors equal to x whose gradients are summed by one kernel (2 <= n <= 4)."""
+    if _is_pair(x):
+        return pair_apply(_ForkN, x, n)
     return _ForkN.apply(x, n)
+
+
+PAIR_SPECS[_ForkN] = ('b-', '', '*')
 
 
 class _Mul(Function):
@@ -1231,7 +1643,12 @@ class _ScaleAddDev(Function):
 
 
 def scale_add(s, a, b):
+    if _is_pair(a):
+        return pair_apply(_ScaleAddDev, s, a, b)
     return _ScaleAddDev.apply(s, a, b)
+
+
+PAIR_SPECS[_ScaleAddDev] = ('-bb', '-h', 'b')
 
 
 class _Recip(Function):
@@ -1299,7 +1716,12 @@ class _LRelu(Function):
 
 
 def leaky_relu(x, slope=0.2):
+    if _is_pair(x):
+        return pair_apply(_LRelu, x, float(slope))
     return _LRelu.apply(x, float(slope))
+
+
+PAIR_SPECS[_LRelu] = ('b-', 'h', 'b')
 
 
 # nn.ELU / nn.SELU (reference trainers/cnn.py:42-44).  SELU = ELU with ATen's constants (torch.selu calls
@@ -1349,11 +1771,18 @@ class _EluBwd(Function):
 
 
 def elu(x, alpha=1.0):
+    if _is_pair(x):
+        return pair_apply(_Elu, x, float(alpha), 1.0)
     return _Elu.apply(x, float(alpha), 1.0)
 
 
 def selu(x):
+    if _is_pair(x):
+        return pair_apply(_Elu, x, SELU_ALPHA, SELU_SCALE)
     return _Elu.apply(x, SELU_ALPHA, SELU_SCALE)
+
+
+PAIR_SPECS[_Elu] = ('b--', 'h', 'b')
 
 
 class _Tanh(Function):
@@ -1474,6 +1903,7 @@ class _AttnBwd(Function):
     discriminator's real branch).  Forward: the fused first-order kernels.  Backward: one fused kernel (tg_attn_dbwd) when
     a wave can hold a row of the map; else the (N x M) maps by GEMM, one row-wise kernel for the softmax algebra
     (tg_attn_dbwd_rows) and GEMMs back down to the operand shapes."""
+    handles_none_grads = True
 
     @staticmethod
     def forward(ctx, go, theta, phi, g, o, lse):
@@ -1546,9 +1976,17 @@ class _AttnCore(Function):
 
 def attention_core(theta, phi, g):
     """theta (B,D,N), phi (B,D,M), g (B,DV,M) -> (B,DV,N).  Fused kernel when the head dims are compiled in."""
-    if K().attn_supported(theta.shape[1], g.shape[1]):
+    fused = K().attn_supported(theta.shape[1], g.shape[1])
+    if _is_pair(theta):
+        if fused:
+            return pair_apply(_AttnCore, theta, phi, g)
+        return Pair(attention_composed(theta.r, phi.r, g.r), attention_composed(theta.f, phi.f, g.f))
+    if fused:
         return _AttnCore.apply(theta, phi, g)
     return attention_composed(theta, phi, g)
+
+
+PAIR_SPECS[_AttnCore] = ('bbb', 'hhhhh', 'b')
 
 
 # =========================================================================== IQN / losses
@@ -1619,8 +2057,14 @@ class _BCELogits(Function):
 
 
 def bce_with_logits(logits, targets):
-    """nn.BCEWithLogitsLoss() (mean reduction)."""
+    """nn.BCEWithLogitsLoss() (mean reduction).  ``logits`` may be a Pair: the loss over the concatenated halves
+    (trainers/cnn.py:124-131 concatenates p_real and p_fake), without the concatenation."""
+    if _is_pair(logits):
+        return pair_apply(_BCELogits, logits, targets)
     return _BCELogits.apply(logits, targets)
+
+
+PAIR_SPECS[_BCELogits] = ('b-', 'h', '-')
 
 
 class _SumSq(Function):

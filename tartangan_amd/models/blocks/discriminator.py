@@ -60,6 +60,9 @@ class ResidualDiscriminatorBlock(nn.Module):
             shortcut = run_layers(self.project_input, shortcut)
         return run_layers(self.convs, x, residual=shortcut)          # x + h, the add fused into the avg-pool
 
+    def default_resampling(self):
+        return self.interpolate is _half
+
     # ---- the first block fused with the from-RGB 1x1 convolution in front of it
     def fuses_with(self, rgb):
         """True if ``rgb`` (a DiscriminatorInput) followed by this block can run as ``forward_from_rgb``: the block starts
@@ -82,8 +85,7 @@ class ResidualDiscriminatorBlock(nn.Module):
         Cout = conv1.weight.shape[0]
         w1 = torch.cat([rgb_conv.weight.view(C, Cimg), rgb_conv.bias.view(C, 1)], 1)                  # (C, Cimg + 1)
         wc = TF.matmul(w1.unsqueeze(0).expand(Cout, C, Cimg + 1), conv1.weight.view(Cout, C, 9), transA=True)
-        ones = img.new_ones(img.shape[0], 1, img.shape[2], img.shape[3])
-        h = TF.conv2d(torch.cat([img, ones], 1), wc.view(Cout, Cimg + 1, 3, 3), conv1.bias)
+        h = TF.conv2d(TF.copy_channels(img, Cimg + 1, 1.0), wc.view(Cout, Cimg + 1, 3, 3), conv1.bias)     # [img, 1] in one pass
         shortcut = run_layers(rgb.convs, self.interpolate(img))
         return run_layers(self.convs[1:], h, residual=shortcut)
 

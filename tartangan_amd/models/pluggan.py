@@ -11,6 +11,7 @@ from collections import namedtuple
 
 from torch import nn
 
+from .. import functional as TF
 from .blocks import (
     DiscriminatorInput, DiscriminatorOutput, GeneratorInputMLP, GeneratorOutput,
     ResidualDiscriminatorBlock, ResidualGeneratorBlock, SelfAttention2d,
@@ -119,6 +120,16 @@ class IQNDiscriminator(Discriminator):
         self.blocks = nn.Sequential(*stages)
 
     def forward(self, x, targets=None):
+        if isinstance(x, TF.Pair):
+            # real | fake as one batch through the blocks; the IQN head runs per half (its rows are quantile-major per
+            # evaluation, and each evaluation draws its own taus: real first, then fake -- iqn.py:118-119)
+            feats = self.blocks(x)
+            n = feats.r.shape[0]
+            out_r = self.to_output(feats.r, targets=None if targets is None else targets[:n])
+            out_f = self.to_output(feats.f, targets=None if targets is None else targets[n:])
+            if targets is None:
+                return TF.Pair(out_r, out_f)
+            return TF.Pair(out_r[0], out_f[0]), (out_r[1], out_f[1])
         return self.to_output(self.blocks(x), targets=targets)
 
 

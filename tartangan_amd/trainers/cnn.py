@@ -83,10 +83,37 @@ class CNNTrainer(Trainer):
 
     # ------------------------------------------------------------------ the step
     def _d_losses(self, real, fake, labels):
-        """-> (p_real, d_loss without penalty); BCE over the concatenated logits (cnn.py:122-131)."""
+        """-> (p_real, d_loss without penalty); BCE over the concatenated logits (cnn.py:122-131).  The two evaluations of
+        D share every kernel launch when the model allows it (``functional.Pair``)."""
+        if self._d_pairable():
+            p = self.d(TF.Pair(real, fake))
+            return p.r, TF.bce_with_logits(p, labels)
         p_real = self.d(real)
         p_fake = self.d(fake)
         return p_real, TF.bce_with_logits(torch.cat([p_real, p_fake], dim=0), labels)
+
+    def _d_pairable(self):
+        """May D(real) and D(fake) of the D phase run as ONE pass over 2B images?  Yes when every module of the discriminator
+        is one of this package's (their forwards understand ``Pair``; a foreign block plugged in through the factory API gets
+        the reference's two separate calls), BatchNorm statistics are local (SyncBN keeps the separate passes), and
+        ``args.pair_d`` (default on) does not say otherwise."""
+        if not getattr(self.args, 'pair_d', True):
+            return False
+        cached = getattr(self, '_pair_ok', None)
+        key = (id(self.d), self.data_parallel is not None and self.data_parallel.sync_bn)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        ok = True
+        for m in self.d.modules():
+            mod = type(m).__module__
+            if not (mod.startswith('tartangan_amd.') or type(m) in (nn.Sequential, nn.Identity, nn.ModuleList)):
+                ok = False
+            if isinstance(m, BatchNorm2d) and m.sync_group is not None:
+                ok = False
+            if isinstance(m, ResidualDiscriminatorBlock) and not m.default_resampling():
+                ok = False
+        self._pair_ok = (key, ok)
+        return ok
 
     def _g_loss(self, fake, ones):
         return TF.bce_with_logits(self.d(fake), ones)

@@ -246,6 +246,26 @@ class Emulator:
             _v(gx, B, C, HW).copy_(r)
         return 0
 
+    # grouped forms = the single-group calls on each group's images, one after the other (what two separate forwards /
+    # backwards of the reference do: trainers/cnn.py:122-123)
+    def bn_train_fwd_groups(self, x, mean, invstd, rm, rv, nbt, gamma, beta, slope, momentum, eps, z, ws, G, B, C, HW, replicate=1):
+        xv, zv = _v(x, G, B * C * HW), _v(z, G, B * C * HW)
+        for g in range(G):
+            self.bn_train_fwd(xv[g], mean[g * C:(g + 1) * C], invstd[g * C:(g + 1) * C], rm, rv, nbt, gamma, beta, slope, momentum,
+                              eps, zv[g], ws, B, C, HW, replicate)
+        return 0
+
+    def bn_act_bwd_groups(self, gz, x, mean, invstd, gamma, beta, slope, training, gx, gg, gb, ws, G, B, C, HW, accumulate,
+                          gx_add=None, add_groups=1):
+        gzv, xv = _v(gz, G, B * C * HW), _v(x, G, B * C * HW)
+        gxv = None if gx is None else _v(gx, G, B * C * HW)
+        addv = None if gx_add is None else _v(gx_add, add_groups, B * C * HW)
+        for g in range(G):
+            self.bn_act_bwd(gzv[g], xv[g], mean[g * C:(g + 1) * C], invstd[g * C:(g + 1) * C], gamma, beta, slope, training,
+                            None if gxv is None else gxv[g], gg, gb, ws, B, C, HW, accumulate if g == 0 else 1,
+                            addv[g] if (addv is not None and g < add_groups) else None)
+        return 0
+
     def bn_act_dbwd(self, v, vg, vb, gz, x, mean, invstd, gamma, beta, slope, a_gz, a_x, a_gamma, ws, B, C, HW, accumulate=0):
         xhat, y, s = self._bn_parts(x, mean, invstd, gamma, beta, slope, B, C, HW)
         n = B * HW
@@ -502,6 +522,14 @@ class Emulator:
 
     def tanh_bwd(self, g, y, out, n):
         out.copy_(g * (1 - y * y))
+        return 0
+
+    def copy_channels(self, src, dst, B, Cs, Cd, HW, fill):
+        sv, dv = _v(src, B, Cs, HW), _v(dst, B, Cd, HW)
+        k = min(Cs, Cd)
+        dv[:, :k].copy_(sv[:, :k])
+        if Cd > Cs:
+            dv[:, Cs:].fill_(fill)
         return 0
 
     def fill(self, x, value, n):

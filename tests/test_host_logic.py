@@ -122,6 +122,14 @@ def test_deferred_wgrad_never_reduces_one_gradient_twice_in_a_launch():
     imgs = synthetic_images(fx['batch'], 32, 7)
     torch.manual_seed(1)
     tr._d_phase(imgs)
+    # real | fake travel as one batch: a weight collects TWO contributions (the paired pass, the R1 second-order term);
+    # with the reference's separate passes it would be three
+    assert len(Recording.calls) == 2
+    tr3 = make_trainer(fx)
+    tr3.args.pair_d = False
+    Recording.calls.clear()
+    torch.manual_seed(1)
+    tr3._d_phase(imgs)
     assert len(Recording.calls) == 3
     for t in Recording.calls:
         dst = t[:, 1].tolist()
@@ -334,3 +342,94 @@ def test_product_has_no_cpu_fallback():
     w = torch.zeros(4, 4, 3, 3)
     with pytest.raises(RuntimeError):
         TF.conv2d(x, w, None)
+
+
+@pytest.mark.parametrize('kind,flags', [('cnn', {}), ('iqn', {}), ('cnn', {'norm': 'id'}), ('cnn', {'activation': 'selu'})])
+def test_paired_discriminator_pass_equals_two_separate_passes(kind, flags, single_thread):
+    """D(real) || D(fake) as ONE pass over 2B images (functional.Pair, grouped BatchNorm) against the reference's two
+    forwards: same losses over two steps, same parameters and BatchNorm buffers after the first (running statistics updated
+    real-then-fake, num_batches_tracked += 2 per layer and D phase), same RNG consumption."""
+    cls = {'cnn': CNNTrainer, 'iqn': IQNTrainer}[kind]
+    attention = () if flags.get('activation') == 'selu' else (1,)       # (the reference's selu init rejects the 0-d gamma)
+    cfg = GAN_CONFIGS['32']._replace(attention=attention)
+    results = []
+    for pair in (True, False):
+        tr = cls(cls.default_args(config=cfg, batch_size=6, device='cpu', pair_d=pair, **flags))
+        torch.manual_seed(0)
+        tr.build_models()
+        tr.g.load_state_dict(procedural_state(tr.g.state_dict(), 7))
+        tr.d.load_state_dict(procedural_state(tr.d.state_dict(), 9))
+        assert tr._d_pairable() == pair
+        imgs = synthetic_images(6, 32, 99)
+        torch.manual_seed(5)
+        logs = [tr.train_batch(imgs)]
+        snap = ({k: v.clone() for k, v in tr.d.state_dict().items()}, {k: v.clone() for k, v in tr.g.state_dict().items()})
+        logs.append(tr.train_batch(imgs))           # (step 2: losses only -- the noise biases below feed the next statistics)
+        results.append((logs, snap[0], snap[1], float(torch.rand(1))))
+    (logs_p, d_p, g_p, rng_p), (logs_s, d_s, g_s, rng_s) = results
+    assert rng_p == rng_s
+    for step, (a, b) in enumerate(zip(logs_p, logs_s)):
+        for k in a:          # (step 2 starts from parameters that already differ by Adam's sign noise, see below)
+            assert _close(a[k], b[k], 2e-5 if step == 0 else 2e-3), (step, k, a, b)
+    # Adam(beta1=0) moves every element by ~lr * sign(gradient) at step 1: an element whose (tiny) gradient flips sign in
+    # the rounding noise differs by 2 lr -- the bound here; the gradients themselves are compared tightly below
+    for name, lr, (p, q) in [('d', 4e-4, (d_p, d_s)), ('g', 1e-4, (g_p, g_s))]:
+        for k in p:
+            if k.endswith('num_batches_tracked'):
+                assert int(p[k]) == int(q[k]), k
+            else:
+                assert float((p[k] - q[k]).abs().max()) <= 2.1 * lr + 1e-6, (name, k, float((p[k] - q[k]).abs().max()))
+
+
+def test_paired_d_phase_leaves_the_batchnorm_buffers_of_two_forwards():
+    """After the D phase alone (no optimiser step in between): the parameter gradients, and running statistics and
+    num_batches_tracked of every BatchNorm of D, equal those of the reference's real-then-fake forwards, tightly."""
+    cfg = GAN_CONFIGS['32']._replace(attention=(1,))
+    states, grads = [], []
+    for pair in (True, False):
+        tr = CNNTrainer(CNNTrainer.default_args(config=cfg, batch_size=6, device='cpu', pair_d=pair))
+        torch.manual_seed(0)
+        tr.build_models()
+        tr.d.load_state_dict(procedural_state(tr.d.state_dict(), 9))
+        torch.manual_seed(5)
+        tr.g.train(); tr.d.train()
+        tr._d_phase(synthetic_images(6, 32, 99))
+        states.append({k: v.clone() for k, v in tr.d.state_dict().items() if 'running' in k or 'num_batches' in k})
+        grads.append({n: p.grad.clone() for n, p in tr.d.named_parameters()})
+    for n in grads[0]:          # ... and the same parameter gradients (first order of both halves + the R1 second-order terms)
+        scale = max(float(grads[1][n].abs().max()), 1e-3)
+        assert float((grads[0][n] - grads[1][n]).abs().max()) <= 2e-5 * scale + 2e-5, n
+    assert states[0].keys() == states[1].keys() and len(states[0]) > 10
+    for k in states[0]:
+        if k.endswith('num_batches_tracked'):
+            assert int(states[0][k]) == int(states[1][k]) == 2, k
+        else:
+            assert torch.allclose(states[0][k], states[1][k], rtol=1e-6, atol=1e-7), k
+
+
+def test_paired_pass_runs_the_r1_penalty_on_the_real_half_only():
+    """Launch accounting on the emulator: with the pair, a D phase runs each forward conv ONCE (on 2B images), the R1
+    first-order pass and its second-order sweep on B images, and the final backward once on 2B."""
+    cfg = GAN_CONFIGS['32']._replace(attention=())
+    calls = []
+
+    class Counting(Emulator):
+        def conv2d_fwd(self, x, w, bias, residual, y, B, *rest):
+            calls.append(('fwd', B))
+            return super().conv2d_fwd(x, w, bias, residual, y, B, *rest)
+
+        def conv2d_dgrad(self, gy, w, gx, B, *rest):
+            calls.append(('dgrad', B))
+            return super().conv2d_dgrad(gy, w, gx, B, *rest)
+
+    prev = backend._set_backend_for_testing(Counting())
+    try:
+        tr = CNNTrainer(CNNTrainer.default_args(config=cfg, batch_size=4, device='cpu'))
+        torch.manual_seed(0)
+        tr.build_models()
+        calls.clear()
+        tr._d_phase(synthetic_images(4, 32, 1))
+    finally:
+        backend._set_backend_for_testing(prev)
+    sizes = {k: sorted({b for kk, b in calls if kk == k}) for k in ('fwd', 'dgrad')}
+    assert sizes['fwd'] == [4, 8] and sizes['dgrad'] == [4, 8], sizes        # 4: generator + R1 passes; 8: the paired D passes

@@ -402,6 +402,63 @@ def test_batchnorm_all_passes(K, shape):
                                     torch.zeros(B, C, HW), rnd(C, seed=13), ws, B, C, HW, 1], [10, 11, 12], tol=5e-5)    # adj_gamma +=
 
 
+# grouped BatchNorm (the discriminator's real and fake batch as one tensor): every code path -- one workgroup per channel
+# (<= 16384 elements per group and channel), the two-launch big-plane path, the generic three-launch path (small planes,
+# many images; odd sizes) -- and the D layers of the benched step (64 + 64 images)
+BN_GROUP_SHAPES = [(2, 4, 16, 64 * 64), (2, 8, 128, 16), (2, 3, 3, 32 * 32), (3, 2, 32, 128 * 128), (2, 5, 100, 8 * 8), (2, 7, 12, 12 * 10),
+                   (2, 130, 24, 16 * 16), (2, 40, 7, 30 * 30), (2, 64, 16, 64 * 64), (2, 64, 32, 32 * 32), (2, 64, 64, 16 * 16),
+                   (2, 64, 128, 8 * 8), (2, 64, 128, 4 * 4), (2, 64, 16, 128 * 128)]
+
+
+@pytest.mark.parametrize('shape', BN_GROUP_SHAPES)
+def test_batchnorm_groups(K, shape):
+    G, B, C, HW = shape
+    x = rnd(G * B, C, HW) * 1.5 + 0.3
+    x[B:] = x[B:] * 0.5 - 1.0                      # the groups' statistics differ
+    gamma, beta = 1 + 0.1 * rnd(C), 0.1 * rnd(C, seed=1)
+    rm, rv = 0.05 * rnd(C, seed=2), 1 + 0.1 * torch.rand(C)
+    ws = workspace(K.bn_workspace(B, G * C, HW))
+    nbt = torch.tensor(41, dtype=torch.int64)
+    for replicate in (1, 4):
+        run_both(K, 'bn_train_fwd_groups', [x, torch.zeros(G * C), torch.zeros(G * C), rm, rv, nbt, gamma, beta, 0.2, 0.1, 1e-5,
+                                            torch.zeros(G * B, C, HW), ws, G, B, C, HW, replicate], [1, 2, 3, 4, 5, 11], tol=1e-5)
+    mean, invstd = torch.zeros(G * C), torch.zeros(G * C)
+    E.bn_train_fwd_groups(x, mean, invstd, None, None, None, gamma, beta, 0.2, 0.1, 1e-5, torch.zeros(G * B, C, HW), None, G, B, C, HW, 1)
+    gz = rnd(G * B, C, HW, seed=5)
+    for slope in (0.2, 1.0):
+        for training in (1, 0):
+            run_both(K, 'bn_act_bwd_groups', [gz, x, mean, invstd, gamma, beta, slope, training, torch.zeros(G * B, C, HW),
+                                              torch.zeros(C), torch.zeros(C), ws, G, B, C, HW, 0, None, 1], [8, 9, 10], tol=3e-5)
+        run_both(K, 'bn_act_bwd_groups', [gz, x, mean, invstd, gamma, beta, slope, 1, None, rnd(C, seed=11), rnd(C, seed=12),
+                                          ws, G, B, C, HW, 1, None, 1], [9, 10], tol=3e-5)
+        # the R1 second-order gradient of the first group's images only, folded into the pass
+        run_both(K, 'bn_act_bwd_groups', [gz, x, mean, invstd, gamma, beta, slope, 1, torch.zeros(G * B, C, HW), torch.zeros(C),
+                                          torch.zeros(C), ws, G, B, C, HW, 0, rnd(B, C, HW, seed=14), 1], [8, 9, 10], tol=3e-5)
+    with pytest.raises(RuntimeError):
+        K.bn_act_bwd_groups(*[a.cuda() if torch.is_tensor(a) else a for a in
+                              [gz, x, mean, invstd, gamma, beta, 0.2, 1, torch.zeros(G * B, C, HW), torch.zeros(C), torch.zeros(C), ws,
+                               G, B, C, HW, 0, rnd(B, C, HW), G + 1]])
+
+
+def test_batchnorm_groups_equal_two_separate_calls_bit_for_bit(K):
+    """One grouped call == the real call followed by the fake call (statistics, outputs, running statistics)."""
+    for (B, C, HW) in [(64, 32, 32 * 32), (64, 128, 8 * 8), (40, 24, 16 * 16)]:
+        x = (rnd(2 * B, C, HW) * 1.3 + 0.2).cuda()
+        gamma, beta = (1 + 0.1 * rnd(C)).cuda(), (0.1 * rnd(C, seed=1)).cuda()
+        ws = workspace(K.bn_workspace(B, 2 * C, HW)).cuda()
+        rm1, rv1, n1 = torch.zeros(C).cuda(), torch.ones(C).cuda(), torch.tensor(0).cuda()
+        rm2, rv2, n2 = torch.zeros(C).cuda(), torch.ones(C).cuda(), torch.tensor(0).cuda()
+        m1, i1, z1 = torch.zeros(2 * C).cuda(), torch.zeros(2 * C).cuda(), torch.zeros(2 * B, C, HW).cuda()
+        m2, i2, z2 = torch.zeros(2 * C).cuda(), torch.zeros(2 * C).cuda(), torch.zeros(2 * B, C, HW).cuda()
+        K.bn_train_fwd_groups(x, m1, i1, rm1, rv1, n1, gamma, beta, 0.2, 0.1, 1e-5, z1, ws, 2, B, C, HW, 1)
+        for g in range(2):
+            K.bn_train_fwd(x[g * B:(g + 1) * B], m2[g * C:(g + 1) * C], i2[g * C:(g + 1) * C], rm2, rv2, n2, gamma, beta, 0.2, 0.1, 1e-5,
+                           z2[g * B:(g + 1) * B], ws, B, C, HW, 1)
+        for a, b in ((m1, m2), (i1, i2), (z1, z2), (rm1, rm2), (rv1, rv2), (n1, n2)):
+            assert torch.equal(a, b), (B, C, HW)
+        assert int(n1) == 2
+
+
 @pytest.mark.parametrize('shape', [(6, 4, 4), (8, 16, 16), (3, 64, 64), (5, 10, 6), (4, 128, 128), (3, 34, 20), (2, 256, 64), (5000, 16, 16)])
 def test_resample(K, shape):
     BC, H, W = shape
