@@ -522,6 +522,132 @@ __global__ void __launch_bounds__(SB) bn_small_bwd_kernel(const float* __restric
   }
 }
 
+// ---- two groups side by side: threads [0, 512) own group 0, [512, 1024) group 1 (32 elements per thread), so the paired
+// real | fake tensor of the discriminator costs ONE small-kernel latency, not two in a row.  Sums are per group (the eight
+// waves of a half); thread 0 then publishes both groups' results in group order.
+constexpr int G2 = 2, SEG2 = SB / G2, PER2 = SMALL_N / SEG2;
+
+// per-group block sum: result of the caller's OWN group in every thread; all 1024 threads must call
+__device__ __forceinline__ double group_sum_d2(double v, double* scratch) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  v = wave_sum_d(v);
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  constexpr int WPG = SEG2 / 64;
+  const int w0 = (wid / WPG) * WPG;
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < WPG; ++i) r += scratch[w0 + i];
+  return r;
+}
+
+__device__ __forceinline__ int small2_off(int e, int HW, int C, int c) {     // offset inside the group (< 2^31: n <= 16384 per channel)
+  const int b = e / HW;
+  return (b * C + c) * HW + (e - b * HW);
+}
+
+__global__ void __launch_bounds__(SB) bn_small_fwd2_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ invstd,
+                                                           float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                           float momentum, float eps, float* __restrict__ z, int B, int C, int HW, int rep) {
+  __shared__ double scratch[32];
+  __shared__ double stat[G2][2];
+  const int c = blockIdx.x;
+  const int g = threadIdx.x / SEG2, t = threadIdx.x - g * SEG2;
+  const int64_t base = (int64_t)g * B * C * HW;
+  const int n_i = B * HW;
+  const float pivot = x[base + (int64_t)c * HW];
+  float xv[PER2];
+#pragma unroll
+  for (int i = 0; i < PER2; ++i) {
+    const int e = t + i * SEG2;
+    xv[i] = e < n_i ? x[base + small2_off(e, HW, C, c)] : pivot;
+  }
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER2; ++i) { const float d = xv[i] - pivot; a0 += d; a1 += d * d; }
+  const double n = (double)n_i;
+  const double s1 = group_sum_d2((double)a0, scratch) / n;
+  const double s2 = group_sum_d2((double)a1, scratch) / n;
+  const double m = (double)pivot + s1;
+  double var = s2 - s1 * s1;
+  if (var < 0.0) var = 0.0;
+  const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)eps));
+  if (t == 0) {
+    mean[g * C + c] = mf;
+    invstd[g * C + c] = rf;
+    stat[g][0] = m; stat[g][1] = var;
+  }
+  const float a = gamma[c] * rf, b = beta[c] - mf * a;
+#pragma unroll
+  for (int i = 0; i < PER2; ++i) {
+    const int e = t + i * SEG2;
+    if (e < n_i) {
+      const float y = bn_y(xv[i], a, b);
+      z[base + small2_off(e, HW, C, c)] = y >= 0.f ? y : y * slope;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (rm != nullptr) {
+      float rmf = rm[c], rvf = rv[c];
+      for (int k = 0; k < G2; ++k) running_update(rmf, rvf, stat[k][0], stat[k][1], n, rep, momentum);
+      rm[c] = rmf; rv[c] = rvf;
+    }
+    if (c == 0 && nbt != nullptr) *nbt += G2;
+  }
+}
+
+__global__ void __launch_bounds__(SB) bn_small_bwd2_kernel(const float* __restrict__ gz, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                           int training, float* __restrict__ gx, float* __restrict__ ggamma,
+                                                           float* __restrict__ gbeta, int B, int C, int HW, int accumulate,
+                                                           const float* __restrict__ add, int add_groups) {
+  __shared__ double scratch[32];
+  __shared__ double tot[G2][2];
+  const int c = blockIdx.x;
+  const int g = threadIdx.x / SEG2, t = threadIdx.x - g * SEG2;
+  const int64_t base = (int64_t)g * B * C * HW;
+  const int n_i = B * HW;
+  const float r = invstd[g * C + c], mu = mean[g * C + c], a = gamma[c] * r, b = beta[c] - mu * a;
+  float gyh[PER2], xh[PER2];
+#pragma unroll
+  for (int i = 0; i < PER2; ++i) {
+    const int e = t + i * SEG2;
+    const bool ok = e < n_i;
+    const int64_t off = base + (ok ? small2_off(e, HW, C, c) : 0);
+    const float xv = ok ? x[off] : mu;
+    const float gg = ok ? gz[off] : 0.f;
+    gyh[i] = bn_y(xv, a, b) >= 0.f ? gg : gg * slope;
+    xh[i] = (xv - mu) * r;
+  }
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER2; ++i) { a0 += gyh[i]; a1 += gyh[i] * xh[i]; }
+  const double n = (double)n_i;
+  const double sb = group_sum_d2((double)a0, scratch), sg = group_sum_d2((double)a1, scratch);
+  if (t == 0) { tot[g][0] = sb; tot[g][1] = sg; }
+  if (gx != nullptr) {
+    const float k1 = (float)(sb / n), k2 = (float)(sg / n);
+    const bool use_add = add != nullptr && g < add_groups;
+#pragma unroll
+    for (int i = 0; i < PER2; ++i) {
+      const int e = t + i * SEG2;
+      if (e < n_i) {
+        const int64_t off = base + small2_off(e, HW, C, c);
+        gx[off] = (training ? a * (gyh[i] - k1 - xh[i] * k2) : a * gyh[i]) + (use_add ? add[off] : 0.f);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gbeta[c] = (float)(tot[0][0] + tot[1][0]) + (accumulate ? gbeta[c] : 0.f);
+    ggamma[c] = (float)(tot[0][1] + tot[1][1]) + (accumulate ? ggamma[c] : 0.f);
+  }
+}
+
 __global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restrict__ v, const float* __restrict__ vgamma,
                                                            const float* __restrict__ vbeta, const float* __restrict__ gz,
                                                            const float* __restrict__ x, const float* __restrict__ mean,
@@ -704,8 +830,12 @@ int tg_bn_train_fwd_groups(const float* x, float* mean, float* invstd, float* ru
   if ((running_mean == nullptr) != (running_var == nullptr)) return TG_EINVAL;
   const int G = groups;
   if (small_case(B, C, HW)) {
-    bn_small_fwd_kernel<<<C, SB, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
-                                                            gamma, beta, slope, momentum, eps, z, B, C, HW, replicate, G);
+    if (G == 2)
+      bn_small_fwd2_kernel<<<C, SB, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
+                                                               gamma, beta, slope, momentum, eps, z, B, C, HW, replicate);
+    else
+      bn_small_fwd_kernel<<<C, SB, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
+                                                              gamma, beta, slope, momentum, eps, z, B, C, HW, replicate, G);
     return tg_launch_status();
   }
   if (planes::big(HW) && tg_aligned16(x) && tg_aligned16(z)) {
@@ -755,8 +885,12 @@ int tg_bn_act_bwd_groups(const float* gz, const float* x, const float* mean, con
   const int G = groups;
   hipStream_t st = tg_stream(stream);
   if (small_case(B, C, HW)) {
-    bn_small_bwd_kernel<<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
-                                             accumulate, gx_add, G, add_groups);
+    if (G == 2)
+      bn_small_bwd2_kernel<<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
+                                                accumulate, gx_add, add_groups);
+    else
+      bn_small_bwd_kernel<<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
+                                               accumulate, gx_add, G, add_groups);
     return tg_launch_status();
   }
   Parts p = split_ws(workspace, B, G * C, HW);

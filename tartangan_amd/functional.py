@@ -809,8 +809,11 @@ class _PoolConvT(Function):
 
 def pool_conv3x3_supported(x, weight):
     B, Cin, H2, W2 = x.shape
-    return (H2 % 2 == 0 and W2 % 2 == 0 and tuple(weight.shape[2:]) == (3, 3)
-            and bool(K().poolconv3x3_supported(B, Cin, weight.shape[0], H2 // 2, W2 // 2)))
+    if not (H2 % 2 == 0 and W2 % 2 == 0 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    # a Pair runs forward / final backward on 2B images but the R1 passes on the real half alone: both batch sizes must
+    # take this form (the kernel's own precondition includes "enough workgroups", which depends on the batch)
+    return all(bool(K().poolconv3x3_supported(b, Cin, weight.shape[0], H2 // 2, W2 // 2)) for b in ((B, B // 2) if _is_pair(x) else (B,)))
 
 
 def pool_conv3x3(x, weight, bias=None, residual=None):

@@ -128,11 +128,18 @@ class CNNTrainer(Trainer):
         fake = self.sample_g(bs)
         labels = torch.zeros(2 * bs, 1, device=self.device)
         labels[:bs] = 1
+        fake = fake.detach()
+        if self._d_pairable() and fake.shape == imgs.shape:
+            # real | fake back to back in ONE buffer: every paired op then sees its input as an alias, not a copy
+            both = imgs.new_empty((2 * bs,) + tuple(imgs.shape[1:]))
+            both[:bs].copy_(imgs)
+            both[bs:].copy_(fake)
+            imgs, fake = both[:bs], both[bs:]
         real = imgs.detach()
         if self.args.grad_penalty:
             real = real.requires_grad_()
         with TF.filter_forms():         # the discriminator's parameters are fixed until its optimiser step
-            p_real, d_loss = self._d_losses(real, fake.detach(), labels)
+            p_real, d_loss = self._d_losses(real, fake, labels)
             d_grad_penalty = None
             if self.args.grad_penalty:
                 d_grad_penalty = TF.scale(gradient_penalty(p_real, real), self.args.grad_penalty)

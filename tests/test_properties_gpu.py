@@ -99,7 +99,8 @@ def _same(a, b, tol):
 
 def test_regular_convs_are_one_trilinear_form_at_full_size(K, step_shapes):
     shapes = sorted(step_shapes['conv2d_fwd'])
-    assert len(shapes) >= 8 and max(s[0] for s in shapes) == FULL['batch']
+    # (the discriminator's real | fake pass runs its layers on 2 x batch images)
+    assert len(shapes) >= 8 and max(s[0] for s in shapes) == 2 * FULL['batch']
     for (B, Cin, Cout, H, W, ks) in shapes:
         x, w, g = _rand(B, Cin, H, W), _rand(Cout, Cin, ks, ks, seed=1, scale=0.1), _rand(B, Cout, H, W, seed=2)
         y, gx, gw = torch.empty_like(g), torch.empty_like(x), torch.empty_like(w)
@@ -114,7 +115,7 @@ def test_regular_convs_are_one_trilinear_form_at_full_size(K, step_shapes):
 @pytest.mark.parametrize('form', ['upconv3x3', 'poolconv3x3'])
 def test_stride2_convs_are_one_trilinear_form_at_full_size(K, step_shapes, form):
     shapes = sorted(step_shapes[form + '_fwd'])
-    assert shapes and max(s[0] for s in shapes) == FULL['batch']
+    assert shapes and max(s[0] for s in shapes) == (2 if form == 'poolconv3x3' else 1) * FULL['batch']
     F = torch.nn.functional
     for (B, Cin, Cout, H, W) in shapes:          # H x W: the low-resolution plane
         w = _rand(Cout, Cin, 3, 3, seed=1, scale=0.1)
