@@ -7,6 +7,8 @@
 //   fwd : z = y*s
 //   bwd : gbeta = S(gyh); ggamma = S(gyh*xhat); gx = gamma*invstd*(gyh - gbeta/n - xhat*ggamma/n)
 //   dbwd: see tg_bn_act_dbwd below (derivation in DESIGN.md "BatchNorm second backward").
+#include <stdlib.h>
+
 #include "planes.h"
 
 namespace {
@@ -402,26 +404,36 @@ static inline int chan_grid(int C) { return (C + 63) / 64; }
 // pure launch latency (~20 us for a few hundred KB).  One kernel, one workgroup per channel: reduce, then apply
 // (the second read hits L2).  Same arithmetic as the large path (fp32 per-thread partials, fp64 combine).
 constexpr int SMALL_N = 16384;
-static inline bool small_case(int B, int C, int HW) { return (int64_t)B * HW <= SMALL_N && C >= 8; }
+static inline int small_n_limit() {            // TG_BN_SMALL_N: development knob (<= SMALL_N), read once
+  static const int v = [] {
+    const char* e = getenv("TG_BN_SMALL_N");
+    const int k = e ? atoi(e) : SMALL_N;
+    return k < 0 ? 0 : (k > SMALL_N ? SMALL_N : k);
+  }();
+  return v;
+}
+static inline bool small_case(int B, int C, int HW) { return (int64_t)B * HW <= small_n_limit() && C >= 8; }
 
 // 1024 threads per channel, <= 16 elements per thread held in registers between the reduce and the apply pass:
 // every global load of a thread is issued up front (independent), nothing is read twice.
 constexpr int SB = 1024, SPER = SMALL_N / SB;
 
-struct SmallIdx {
-  int64_t off[SPER];
-  bool ok[SPER];
-  __device__ __forceinline__ SmallIdx(int B, int C, int HW, int c, int64_t base = 0) {
+template <int N, int THREADS = SB>
+struct SmallIdxN {
+  int64_t off[N];
+  bool ok[N];
+  __device__ __forceinline__ SmallIdxN(int B, int C, int HW, int c, int64_t base = 0) {
     const int n = B * HW;
 #pragma unroll
-    for (int i = 0; i < SPER; ++i) {
-      const int e = threadIdx.x + i * SB;
+    for (int i = 0; i < N; ++i) {
+      const int e = threadIdx.x + i * THREADS;
       const int b = e / HW, p = e - b * HW;
       ok[i] = e < n;
       off[i] = base + ((int64_t)b * C + c) * HW + p;
     }
   }
 };
+using SmallIdx = SmallIdxN<SPER>;
 
 __device__ __forceinline__ double block_sum_d1024(double v, double* scratch) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -437,13 +449,15 @@ __device__ __forceinline__ double block_sum_d1024(double v, double* scratch) {
 
 // One workgroup per CHANNEL; its G groups (B images each) are normalised one after the other, so the running statistics
 // are updated in group order.
+template <int GT>
 __global__ void __launch_bounds__(SB) bn_small_fwd_kernel(const float* __restrict__ x, float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
                                                           float momentum, float eps, float* __restrict__ z, int B, int C, int HW, int rep,
-                                                          int G) {
+                                                          int Grt) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
+  const int G = GT > 0 ? GT : Grt;
   float rmf = 0.f, rvf = 0.f;
   if (rm != nullptr) { rmf = rm[c]; rvf = rv[c]; }
   const double n = (double)B * HW;
@@ -482,14 +496,16 @@ __global__ void __launch_bounds__(SB) bn_small_fwd_kernel(const float* __restric
   }
 }
 
+template <int GT>
 __global__ void __launch_bounds__(SB) bn_small_bwd_kernel(const float* __restrict__ gz, const float* __restrict__ x,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
                                                           int training, float* __restrict__ gx, float* __restrict__ ggamma,
                                                           float* __restrict__ gbeta, int B, int C, int HW, int accumulate,
-                                                          const float* __restrict__ add, int G, int add_groups) {
+                                                          const float* __restrict__ add, int Grt, int add_groups) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
+  const int G = GT > 0 ? GT : Grt;
   const double n = (double)B * HW;
   double tb = 0.0, tg = 0.0;
   for (int g = 0; g < G; ++g) {
@@ -648,7 +664,21 @@ __global__ void __launch_bounds__(SB) bn_small_bwd2_kernel(const float* __restri
   }
 }
 
-__global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restrict__ v, const float* __restrict__ vgamma,
+// (<= DSMALL_N elements per channel, 512 threads x 8: the fp64 coefficient algebra needs more than the 128 registers a
+// 1024-thread workgroup leaves a lane -- as a 1024 x 16 kernel this one spilled 148 of them)
+constexpr int DSMALL_N = 4096, DSB = 512, DPER = DSMALL_N / DSB;
+__device__ __forceinline__ double block_sum_d512(double v, double* scratch) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  v = wave_sum_d(v);
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < DSB / 64; ++i) r += scratch[i];
+  return r;
+}
+__global__ void __launch_bounds__(DSB) bn_small_dbwd_kernel(const float* __restrict__ v, const float* __restrict__ vgamma,
                                                            const float* __restrict__ vbeta, const float* __restrict__ gz,
                                                            const float* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -657,11 +687,11 @@ __global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restri
                                                            int accumulate) {
   __shared__ double scratch[32];
   const int c = blockIdx.x;
-  const SmallIdx ix(B, C, HW, c);
+  const SmallIdxN<DPER, DSB> ix(B, C, HW, c);
   const float r = invstd[c], mu = mean[c], gr = gamma[c] * r, b = beta[c] - mu * gr;
-  float vv[SPER], gyh[SPER], xh[SPER], sl[SPER];
+  float vv[DPER], gyh[DPER], xh[DPER], sl[DPER];
 #pragma unroll
-  for (int i = 0; i < SPER; ++i) {
+  for (int i = 0; i < DPER; ++i) {
     const float xv = ix.ok[i] ? x[ix.off[i]] : mu;
     vv[i] = ix.ok[i] ? v[ix.off[i]] : 0.f;
     const float g = ix.ok[i] ? gz[ix.off[i]] : 0.f;
@@ -671,13 +701,13 @@ __global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restri
   }
   float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < SPER; ++i) {
+  for (int i = 0; i < DPER; ++i) {
     acc[0] += vv[i]; acc[1] += vv[i] * xh[i]; acc[2] += gyh[i]; acc[3] += gyh[i] * xh[i]; acc[4] += vv[i] * gyh[i];
   }
   const double n = (double)B * HW;
-  const double S1 = block_sum_d1024((double)acc[0], scratch), S2 = block_sum_d1024((double)acc[1], scratch);
-  const double S3 = block_sum_d1024((double)acc[2], scratch), S4 = block_sum_d1024((double)acc[3], scratch);
-  const double S5 = block_sum_d1024((double)acc[4], scratch);
+  const double S1 = block_sum_d512((double)acc[0], scratch), S2 = block_sum_d512((double)acc[1], scratch);
+  const double S3 = block_sum_d512((double)acc[2], scratch), S4 = block_sum_d512((double)acc[3], scratch);
+  const double S5 = block_sum_d512((double)acc[4], scratch);
   const double rd = (double)r, g = (double)gamma[c];
   const double vg = vgamma ? (double)vgamma[c] : 0.0;
   const double A = S5 - S1 * S3 / n - S2 * S4 / n;
@@ -689,7 +719,7 @@ __global__ void __launch_bounds__(SB) bn_small_dbwd_kernel(const float* __restri
   const float vgf = (float)vg, vbf = vbeta ? vbeta[c] : 0.f;
   if (threadIdx.x == 0) adj_gamma[c] = (float)(rd * A) + (accumulate ? adj_gamma[c] : 0.f);
 #pragma unroll
-  for (int i = 0; i < SPER; ++i)
+  for (int i = 0; i < DPER; ++i)
     if (ix.ok[i]) {
       const float pv = vv[i] - k0 - xh[i] * k1;
       adj_gz[ix.off[i]] = (gr * pv + vgf * xh[i] + vbf) * sl[i];
@@ -833,9 +863,12 @@ int tg_bn_train_fwd_groups(const float* x, float* mean, float* invstd, float* ru
     if (G == 2)
       bn_small_fwd2_kernel<<<C, SB, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
                                                                gamma, beta, slope, momentum, eps, z, B, C, HW, replicate);
+    else if (G == 1)
+      bn_small_fwd_kernel<1><<<C, SB, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
+                                                                 gamma, beta, slope, momentum, eps, z, B, C, HW, replicate, G);
     else
-      bn_small_fwd_kernel<<<C, SB, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
-                                                              gamma, beta, slope, momentum, eps, z, B, C, HW, replicate, G);
+      bn_small_fwd_kernel<0><<<C, SB, 0, tg_stream(stream)>>>(x, mean, invstd, running_mean, running_var, num_batches_tracked,
+                                                                 gamma, beta, slope, momentum, eps, z, B, C, HW, replicate, G);
     return tg_launch_status();
   }
   if (planes::big(HW) && tg_aligned16(x) && tg_aligned16(z)) {
@@ -888,9 +921,12 @@ int tg_bn_act_bwd_groups(const float* gz, const float* x, const float* mean, con
     if (G == 2)
       bn_small_bwd2_kernel<<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
                                                 accumulate, gx_add, add_groups);
+    else if (G == 1)
+      bn_small_bwd_kernel<1><<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
+                                                  accumulate, gx_add, G, add_groups);
     else
-      bn_small_bwd_kernel<<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
-                                               accumulate, gx_add, G, add_groups);
+      bn_small_bwd_kernel<0><<<C, SB, 0, st>>>(gz, x, mean, invstd, gamma, beta, slope, training, gx, ggamma, gbeta, B, C, HW,
+                                                  accumulate, gx_add, G, add_groups);
     return tg_launch_status();
   }
   Parts p = split_ws(workspace, B, G * C, HW);
@@ -927,8 +963,8 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, cons
   TG_CHECK_PTR(beta); TG_CHECK_PTR(adj_gz); TG_CHECK_PTR(adj_x); TG_CHECK_PTR(adj_gamma); TG_CHECK_PTR(workspace);
   TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(HW);
   hipStream_t st = tg_stream(stream);
-  if (small_case(B, C, HW) && (int64_t)B * HW <= 4096) {
-    bn_small_dbwd_kernel<<<C, SB, 0, st>>>(v, vgamma, vbeta, gz, x, mean, invstd, gamma, beta, slope, adj_gz, adj_x, adj_gamma,
+  if (small_case(B, C, HW) && (int64_t)B * HW <= DSMALL_N) {
+    bn_small_dbwd_kernel<<<C, DSB, 0, st>>>(v, vgamma, vbeta, gz, x, mean, invstd, gamma, beta, slope, adj_gz, adj_x, adj_gamma,
                                               B, C, HW, accumulate);
     return tg_launch_status();
   }

@@ -134,9 +134,9 @@ def test_stride2_step_shapes_full_batch_after_lds_poison(K, shape):
     if K.upconv3x3_dgrad_supported(B, Cin, Cout, H, W):        # (4x4 source planes take the composed path in the layer)
         poison_lds(K)
         run_both(K, 'upconv3x3_dgrad', [gyh, w4t, torch.zeros(B, Cin, H, W), B, Cin, Cout, H, W], [2], tol=5e-5)
-    ws = workspace(K.upconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
-    poison_lds(K)
-    run_both(K, 'upconv3x3_wgrad', [a, gyh, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0], [2], tol=1e-4, scratch=[3])
+        ws = workspace(K.upconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
+        poison_lds(K)
+        run_both(K, 'upconv3x3_wgrad', [a, gyh, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0], [2], tol=1e-4, scratch=[3])
     x, gy = rnd(B, Cin, 2 * H, 2 * W, seed=5), rnd(B, Cout, H, W, seed=6)
     w4, wpp = torch.zeros(Cout, Cin, 4, 4), torch.zeros(4, Cin, Cout, 2, 2)
     E.poolconv3x3_weights(w, w4, wpp, Cout, Cin)
@@ -145,9 +145,9 @@ def test_stride2_step_shapes_full_batch_after_lds_poison(K, shape):
         run_both(K, 'poolconv3x3_fwd', [x, w4, b, None, torch.zeros(B, Cout, H, W), B, Cin, Cout, H, W], [4], tol=5e-5)
         poison_lds(K)
         run_both(K, 'poolconv3x3_dgrad', [gy, wpp, torch.zeros(B, Cin, 2 * H, 2 * W), B, Cin, Cout, H, W], [2], tol=5e-5)
-    ws = workspace(K.poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
-    poison_lds(K)
-    run_both(K, 'poolconv3x3_wgrad', [x, gy, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0], [2], tol=1e-4, scratch=[3])
+        ws = workspace(K.poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
+        poison_lds(K)
+        run_both(K, 'poolconv3x3_wgrad', [x, gy, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0], [2], tol=1e-4, scratch=[3])
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 16, 64, 64), (3, 32, 16, 32, 32), (2, 64, 32, 16, 16), (5, 128, 128, 8, 8), (20, 128, 128, 4, 4),
