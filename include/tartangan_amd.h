@@ -241,6 +241,14 @@ int tg_pool2(const float* x, const float* residual /*nullable: y = residual + po
 int tg_bilinear_half_fwd(const float* x, float* y, int BC, int H, int W, void* stream);
 int tg_bilinear_half_bwd(const float* gy, const float* residual /*nullable, shape of gx*/, float* gx,
                          int BC, int H, int W, void* stream);
+/* Input side of the FID / Inception-score pipeline (8f-2).  out (B, C, OH, OW) = bilinear resize (align_corners=True;
+ * F.interpolate(x, size=(299, 299), mode='bilinear', align_corners=True), inception_utils.py:49-50) of x (B, C, H, W) after
+ * `stages` applications of  x <- ((x + 1) / 2 - mean[c]) / std[c]  -- one in WrapInception.forward (inception_utils.py:44-47), a
+ * second, identical one in accumulate_inception_activations' transform (:254-258), which the reference applies to the
+ * generator's samples before WrapInception sees them.  stages = 0: resize only; OH == H and OW == W: normalise only. */
+int tg_inception_preprocess(const float* x, const float* mean /*[C]*/, const float* stdv /*[C]*/, float* out,
+                            int B, int C, int H, int W, int OH, int OW, int stages, void* stream);
+
 /* F.max_pool2d(x,[2,2]) attention.py:25-26; idx = argmax position 0..3 inside the window
  * (first maximum in row-major window order, like ATen)                          */
 int tg_maxpool2_fwd(const float* x, float* y, uint8_t* idx, int BC, int H, int W, void* stream);

@@ -296,6 +296,45 @@ __global__ void __launch_bounds__(RS_BLOCK) maxpool2_gather_kernel(const float* 
 
 }  // namespace
 
+// ---- Inception input (8f-2): the reference hands its samples to the Inception network through
+// accumulate_inception_activations' transform (inception_utils.py:254-258: (s + 1) / 2, then (s - VGG_MEAN) / VGG_STD) and
+// WrapInception.forward (:44-50: the SAME normalisation once more, then F.interpolate(size=(299, 299), mode='bilinear',
+// align_corners=True)).  One kernel: `stages` normalisations (per source pixel, in the reference's operation order:
+// add, divide by 2, subtract, divide), then ATen's align_corners bilinear weights.  Streaming, HBM-bound
+// (4 B out per sample; the four source pixels of neighbouring outputs come from L2).
+__device__ __forceinline__ float inception_norm(float v, float m, float sd, int stages) {
+  for (int k = 0; k < stages; ++k) {
+    v = (v + 1.f) / 2.0f;
+    v = (v - m) / sd;
+  }
+  return v;
+}
+__global__ void __launch_bounds__(RS_BLOCK) inception_preprocess_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                        const float* __restrict__ stdv, float* __restrict__ out, int C, int H,
+                                                                        int W, int OH, int OW, int stages, float rh, float rw, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)RS_BLOCK + threadIdx.x; i < total; i += gridDim.x * (int64_t)RS_BLOCK) {
+    const int ow = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oh = (int)(t % OH);
+    const int64_t plane = t / OH;
+    const int c = (int)(plane % C);
+    const float m = mean[c], sd = stdv[c];
+    const float* src = x + plane * (int64_t)H * W;
+    if (H == OH && W == OW) {
+      out[i] = inception_norm(src[(int64_t)oh * W + ow], m, sd, stages);
+      continue;
+    }
+    const float h1r = rh * oh, w1r = rw * ow;
+    const int h1 = (int)h1r, w1 = (int)w1r;
+    const int h1p = h1 < H - 1 ? 1 : 0, w1p = w1 < W - 1 ? 1 : 0;
+    const float h1l = h1r - h1, h0l = 1.f - h1l, w1l = w1r - w1, w0l = 1.f - w1l;
+    const float* p = src + (int64_t)h1 * W + w1;
+    const float v00 = inception_norm(p[0], m, sd, stages), v01 = inception_norm(p[w1p], m, sd, stages);
+    const float v10 = inception_norm(p[(int64_t)h1p * W], m, sd, stages), v11 = inception_norm(p[(int64_t)h1p * W + w1p], m, sd, stages);
+    out[i] = h0l * (w0l * v00 + w1l * v01) + h1l * (w0l * v10 + w1l * v11);
+  }
+}
+
 extern "C" {
 
 int tg_up2x(const float* x, float* y, float alpha, int BC, int H, int W, void* stream) {
@@ -382,6 +421,20 @@ int tg_maxpool2_gather(const float* x, const uint8_t* idx, float* y, int BC, int
   if (H < 2 || W < 2 || (H & 1) || (W & 1)) return TG_EUNSUPPORTED;
   const int64_t nout = (int64_t)BC * (H / 2) * (W / 2);
   maxpool2_gather_kernel<<<tg_ew_grid(nout, RS_BLOCK), RS_BLOCK, 0, tg_stream(stream)>>>(x, idx, y, nout, H, W);
+  return tg_launch_status();
+}
+
+int tg_inception_preprocess(const float* x, const float* mean, const float* stdv, float* out, int B, int C, int H, int W, int OH, int OW,
+                            int stages, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(mean); TG_CHECK_PTR(stdv); TG_CHECK_PTR(out);
+  TG_CHECK_POS(B); TG_CHECK_POS(C); TG_CHECK_POS(H); TG_CHECK_POS(W); TG_CHECK_POS(OH); TG_CHECK_POS(OW);
+  if (stages < 0 || stages > 4) return TG_EINVAL;
+  const int64_t total = (int64_t)B * C * OH * OW;
+  // ATen's area_pixel_compute_scale for align_corners=True: (in - 1) / (out - 1) in fp32, 0 for a single output row / column
+  const float rh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float rw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  inception_preprocess_kernel<<<tg_ew_grid(total, RS_BLOCK), RS_BLOCK, 0, tg_stream(stream)>>>(x, mean, stdv, out, C, H, W, OH, OW, stages,
+                                                                                                rh, rw, total);
   return tg_launch_status();
 }
 

@@ -4,5 +4,6 @@ checkpoint / resume and the progress sampler.  Same class names, hooks and file 
 from .base import TrainerComponent
 from .image_sampler import ImageSamplerComponent
 from .model_checkpoint import ModelCheckpointComponent
+from .metrics import FIDComponent
 
-__all__ = ['TrainerComponent', 'ImageSamplerComponent', 'ModelCheckpointComponent']
+__all__ = ['TrainerComponent', 'ImageSamplerComponent', 'ModelCheckpointComponent', 'FIDComponent']

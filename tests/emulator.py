@@ -426,6 +426,16 @@ class Emulator:
         _v(gx, BC, H, W).copy_(g[0] if residual is None else _v(residual, BC, H, W) + g[0])
         return 0
 
+    def inception_preprocess(self, x, mean, stdv, out, B, C, H, W, OH, OW, stages):
+        v = _v(x, B, C, H, W)
+        for _ in range(stages):
+            v = (v + 1.) / 2.0
+            v = (v - mean.view(1, C, 1, 1)) / stdv.view(1, C, 1, 1)
+        if (H, W) != (OH, OW):
+            v = F.interpolate(v, size=(OH, OW), mode='bilinear', align_corners=True)
+        _v(out, B, C, OH, OW).copy_(v)
+        return 0
+
     def maxpool2_fwd(self, x, y, idx, BC, H, W):
         xv = _v(x, BC, H // 2, 2, W // 2, 2).permute(0, 1, 3, 2, 4).reshape(BC, H // 2, W // 2, 4)
         # first maximum in window order (NaN-free inputs)

@@ -48,8 +48,45 @@ def run(name):
     return out
 
 
+def run_frontend():
+    """The input side: the reference's own accumulate_inception_activations + WrapInception (normalise twice, resize to
+    299 x 299, run the wrapped network's layers, softmax) around a stand-in network with torchvision's attribute names."""
+    from oracle.fid_features import blocky_images, tiny_inception
+    D, classes, batch, size, want = 64, 10, 8, 32, 40
+    inner = tiny_inception(D, classes, 5)
+    net = R.WrapInception(inner)
+    seen = []
+    inner.Conv2d_1a_3x3.register_forward_pre_hook(lambda m, inp: seen.append(inp[0].detach().clone()))
+    calls = [0]
+
+    def sample():
+        calls[0] += 1
+        return blocky_images(batch, size, 700 + calls[0])
+    pool, probs = R.accumulate_inception_activations(sample, net, want)
+    out = dict(D=D, classes=classes, batch=batch, size=size, want=want, calls=calls[0], n=int(pool.shape[0]),
+               preprocessed_first_batch=summarize(seen[0], 16), pool=summarize(pool, 16), probs=summarize(probs, 16))
+    m, s = R.calculate_inception_score(probs.numpy(), 5)
+    data = procedural_features(200, D, 12, shift=0.25)
+    mu2, s2 = torch.mean(data, 0), R.torch_cov(data.clone(), rowvar=False)
+    mu1, s1 = torch.mean(pool, 0), R.torch_cov(pool.clone(), rowvar=False)
+    out.update(is_mean=float(m), is_std=float(s), fid=float(R.torch_calculate_frechet_distance(mu1, s1, mu2, s2)),
+               data_features=dict(n=200, seed=12, shift=0.25))
+    # a non-square, non-multiple-of-anything source size through WrapInception alone (one normalisation)
+    x = blocky_images(3, 40, 901)[:, :, :, :27].contiguous()
+    seen.clear()
+    net(x)
+    out['wrap_only_40x27'] = summarize(seen[0], 16)
+    print('frontend', {k: v for k, v in out.items() if not isinstance(v, dict)}, flush=True)
+    return out
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    if sys.argv[1:] == ['frontend']:
+        path = os.path.join(HERE, 'fid_frontend.json')
+        json.dump(run_frontend(), open(path, 'w'), separators=(',', ':'))
+        print('wrote', path)
+        sys.exit(0)
     res = {n: run(n) for n in (sys.argv[1:] or CASES)}
     path = os.path.join(HERE, 'fid_math.json')
     old = json.load(open(path)) if os.path.exists(path) else {}

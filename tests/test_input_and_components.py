@@ -327,3 +327,44 @@ def test_draws_outside_a_step_bypass_the_recorded_rng_plan(tmp_path, emulated):
     assert float(torch.rand(1)) == after
     assert logs == want
     assert torch.equal(sm.progress_samples, sm2.progress_samples)
+
+
+def test_fid_component_hooks_and_flags(tmp_path, emulated):
+    """metrics/fid.py:13-46: every fid_freq batches (IS mean, IS std, FID) from trainer.sample_g batches are appended to
+    the step's logs; same flags as the reference.  The network is a stand-in with torchvision's attribute names."""
+    import argparse
+    from oracle.fid_features import procedural_features, tiny_inception
+    from tartangan_amd.trainers.components import FIDComponent
+    p = argparse.ArgumentParser()
+    FIDComponent.add_args_to_parser(p)
+    flags = p.parse_args(['--n-inception-imgs', '12', '--fid-freq', '2'])
+    assert flags.inception_moments is None and not flags.cleanup_inception_model
+    data = procedural_features(60, 16, 3).double().numpy()
+    path = os.path.join(tmp_path, 'moments.npz')
+    np.savez(path, mu=data.mean(0), sigma=np.cov(data, rowvar=False))
+    tr = _trainer(tmp_path)
+    for k, v in vars(flags).items():
+        setattr(tr.args, k, v)
+    tr.args.inception_moments = path
+    fid = FIDComponent(tr.args, net=tiny_inception(16, 5, 1))
+    tr.attach(fid)
+    fid.on_train_begin(0, {})
+    logs = {}
+    fid.on_batch_end(1, logs)
+    assert logs == {}
+    torch.manual_seed(4)
+    fid.on_batch_end(2, logs)                          # 12 images = 3 sample_g() batches of 4
+    assert set(logs) == {'fid', 'inception_score_mean', 'inception_score_std'} and len(logs['fid']) == 1
+    assert np.isfinite(logs['fid'][0]) and logs['inception_score_mean'][0] >= 1.0
+    torch.manual_seed(4)
+    z = torch.randn(4, tr.gan_config.latent_dims)      # the sampling consumed the default generator batch by batch
+    torch.randn(4, tr.gan_config.latent_dims); torch.randn(4, tr.gan_config.latent_dims)
+    after = float(torch.rand(1))
+    torch.manual_seed(4)
+    fid.on_batch_end(4, logs)
+    assert float(torch.rand(1)) == after and len(logs['fid']) == 2
+    fid.on_train_end(4, logs)
+    bare = FIDComponent(tr.args)                       # no network handed in: the pretrained weights cannot be fetched here
+    tr.attach(bare)
+    with pytest.raises(RuntimeError, match='pretrained|Inception'):
+        bare.on_train_begin(0, {})
