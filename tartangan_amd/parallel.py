@@ -9,9 +9,10 @@ At these sizes the collectives are latency-bound; there is nothing to bucket fur
 Overlap (``overlap=True``, the default on a device): both all-reduces are issued on a side stream
 that waits for the producing backward, and are joined only where their result is consumed --
 the D bucket right before D's Adam step, i.e. after the G phase's generator forward (which needs
-no discriminator weights; trainers.cnn._g_forward), the G bucket right before G's Adam step (in the default schedule that is
-immediately: the collective is exposed; ``trainers.cnn`` with ``defer_g_update`` hides it under the next step's D(real)
-forward and R1 first-order pass, which read no generator weight).  The serial schedule
+no discriminator weights; trainers.cnn._g_forward), the G bucket right before G's Adam step, i.e. immediately: that collective (5.1 MB, latency-bound) is
+exposed.  The only generator-independent work of the next step -- D(real) forward and the R1 first-order pass -- now runs
+fused with D(fake) as one 2B pass (``functional.Pair``), which needs the generator's new samples first; un-pairing it to
+hide ~50-100 us of collective would cost ~0.5 ms of step time (DESIGN.md "Multi-GPU").  The serial schedule
 (``overlap=False``) issues the same collectives on the compute stream; both give bit-identical
 parameters (tests/test_dp_gloo.py).
 

@@ -111,10 +111,8 @@ CASES = {
     'c512thin_test_cnn_b2': ('512thin-test', 'cnn', 2, 1),
     # the remaining families of pluggan.GAN_CONFIGS: the smallest, a 256 px one (with and without attention), the wide one
     'c16_cnn_b16': ('16', 'cnn', 16, 2),
-    'c256a3_cnn_b2': ('256:3', 'cnn', 2, 1),
     'c256_iqn_b2': ('256', 'iqn', 2, 1),
-    'c128big_cnn_b2': ('128big', 'cnn', 2, 1),
-    # batch-8 versions of the two fixtures whose batch-2 BatchNorm statistics sit on a knife edge (tools/knife_edge.py)
+    # (batch 8: at batch 2 the BatchNorm statistics of these two sat on a knife edge, tools/knife_edge.py)
     'c256a3_cnn_b8': ('256:3', 'cnn', 8, 1),
     'c128big_cnn_b8': ('128big', 'cnn', 8, 1),
     # BASELINE.json config 4 at its GLOBAL batch (256 = 8 GPUs x 32; replayed as 4 ranks x 64 with SyncBN on one GPU)

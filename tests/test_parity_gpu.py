@@ -25,10 +25,10 @@ def hip_backend():
 # pre-activation sits within rounding of 0: the reference itself (CPU oracle, fp32) moves gp by exactly 1.3e-4 in
 # 3 of 12 trials when the input images are perturbed by 1e-7 relative (tools: /tmp-style experiment recorded in
 # DESIGN.md "Knife-edge masks").  Any change of summation order can land on either side, so the bound is 3e-4 here.
-# The two batch-2 fixtures: tools/knife_edge.py (the CPU oracle = the reference's arithmetic, six trials with the input images
-# perturbed by 1e-7 relative) moves g_loss by 1.3e-4 (256:3) / 4.7e-3 (128big, where d_loss and gp are bimodal too: +-1.2e-4)
-# -- BatchNorm over two images and D's first Adam step (+-lr per weight, sign decided by rounding where the gradient is ~0).
-KNIFE_EDGE = {'c128a3_iqn_b4': 3e-4, 'c256a3_cnn_b2': 4e-4, 'c128big_cnn_b2': 8e-3}
+# (Round 2's two batch-2 fixtures -- BatchNorm over two images: g_loss moved by up to 4.7e-3 under a 1e-7 input perturbation in
+# the reference's own arithmetic, tools/knife_edge.py -- are replaced by batch-8 fixtures of the same configurations,
+# c256a3_cnn_b8 / c128big_cnn_b8, held to the common 1e-4.)
+KNIFE_EDGE = {'c128a3_iqn_b4': 3e-4}
 
 
 def _close(a, b, rel, abs_=1e-6):
@@ -82,6 +82,12 @@ def test_hip_trainer_matches_reference_fixture(case):
                 ref_s = fx['after_step1']['d_grad'][name]
                 got = summarize(p.grad, len(ref_s['idx']))
                 assert _close(got['l2'], ref_s['l2'], 2e-3, 5e-5 * ref['d_grad_l2']), ('d_grad', name, got['l2'], ref_s['l2'])
+            # per-tensor G gradients (taken after D's first Adam step: the loose bound explained above, tensor by tensor;
+            # tight pins from identical D state: test_g_phase_gradients_match_oracle)
+            for name, p in tr.g.named_parameters():
+                ref_s = fx['after_step1']['g_grad'][name]
+                got = summarize(p.grad, len(ref_s['idx']))
+                assert _close(got['l2'], ref_s['l2'], g_grad_tol, 2e-3 * ref['g_grad_l2']), ('g_grad', name, got['l2'], ref_s['l2'])
     assert float(torch.rand(1)) == fx['rng_after']          # z / tau RNG stream consumed like the reference
 
 
@@ -127,7 +133,7 @@ def _adam_flat(opt, params, key):
     return pack([opt.state[p][key] for p in params], params[0])
 
 
-@pytest.mark.parametrize('case', ['c32_cnn_b16', 'c32a2_iqn_b8', 'c64a1_cnn_b8', 'c64a1_iqn_b8', 'c128a3_cnn_b4'])
+@pytest.mark.parametrize('case', ['c32_cnn_b16', 'c32a2_iqn_b8', 'c64a1_cnn_b8', 'c64a1_iqn_b8', 'c128a3_cnn_b4', 'c128a3_cnn_b64'])
 def test_step2_from_resynchronised_state(case):
     """Steps >= 2 of a free-running comparison are only sanity-bounded (GAN steps amplify rounding chaotically).  Here
     step 2 is pinned at the step-1 tolerance instead: the CPU oracle (itself pinned to the reference's steps 1-3 at 2e-5,
@@ -136,9 +142,8 @@ def test_step2_from_resynchronised_state(case):
     images and RNG stream.  1e-4 on the three losses, like step 1; the reference's own step-2 numbers are checked too."""
     from oracle import sagan_cpu as O
     fx = load_golden(case)
-    if len(fx['steps']) < 2:
-        pytest.skip('fixture holds one step')
-    torch.set_num_threads(8)
+    has_step2 = len(fx['steps']) >= 2          # (the benched-size fixture holds the reference's step 1 only: step 2 is oracle vs HIP)
+    torch.set_num_threads(min(32, max(8, (torch.get_num_threads() or 8))) if fx['batch'] >= 64 else 8)
     torch.manual_seed(0)
     ref = O.OracleTrainer(fx['config'], fx['trainer'], fx['batch'], attention=fx['attention'])
     ref.load(g=procedural_state(ref.g, fx['weight_seed']), target_g=procedural_state(ref.target_g, fx['weight_seed'] + 1),
@@ -166,9 +171,11 @@ def test_step2_from_resynchronised_state(case):
         assert _close(got[name], want[name], tol), (case, name, got[name], want[name])
         # (the oracle is pinned to the reference's step 2 at 2e-5 single-threaded in the build container; on this host's
         # CPU and thread count its free-running step 2 may already sit ~1e-4 away -- the chaos this test sidesteps)
-        assert _close(want[name], fx['steps'][1][name], 5e-3), ('oracle vs reference step 2', name)
-    assert _close(_total_l2(tr.d), fx['steps'][1]['d_l2'], 1e-4)
-    assert _close(_total_l2(tr.g), fx['steps'][1]['g_l2'], 1e-4)
+        if has_step2:
+            assert _close(want[name], fx['steps'][1][name], 5e-3), ('oracle vs reference step 2', name)
+    if has_step2:
+        assert _close(_total_l2(tr.d), fx['steps'][1]['d_l2'], 1e-4)
+        assert _close(_total_l2(tr.g), fx['steps'][1]['g_l2'], 1e-4)
 
 
 def test_forward_pins_and_iqn_tau_exactness():
