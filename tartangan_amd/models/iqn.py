@@ -35,6 +35,11 @@ class IQN(nn.Module):
         self._device = None
         self.tau_source = None      # optional callable(rows, num_quantiles) -> (rows, 1) device tensor
 
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['tau_source'] = None          # a trainer's hook (bound to its RNG feed): not part of a pickled model
+        return state
+
     def forward(self, x):
         batch_size = x.shape[0]
         x = TF.repeat_rows(x, self.num_quantiles)               # (Q*B, C), row = q*B + b

@@ -308,6 +308,8 @@ def test_draws_outside_a_step_bypass_the_recorded_rng_plan(tmp_path, emulated):
     logs = [tr.train_batch(imgs)]
     plan = list(tr.rng_feed.plan)
     assert plan and ('z', 32, tr.gan_config.latent_dims) not in plan and len(plan) == 5
+    torch.save(tr.d, f'{tmp_path}/d_with_hook.pt')    # the tau hook the trainer installed on the IQN head does not travel
+    assert torch.load(f'{tmp_path}/d_with_hook.pt', weights_only=False).to_output.iqn.tau_source is None
     sm.on_batch_end(0, {})                            # sample_z(4) == the batch size: must not alias the step's z buffer
     assert tr.rng_feed.plan == plan
     assert all(sm._latent_grid_samples.data_ptr() != b.data_ptr() for b in tr.rng_feed.static)
