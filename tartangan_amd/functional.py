@@ -137,6 +137,48 @@ def _param_grads_wanted():
     return not _InputGradsOnly.active
 
 
+class _ParamsOnly:
+    active = False
+
+
+@contextlib.contextmanager
+def params_only():
+    """The mirror image of ``input_grads_only``: the enclosing backward asks for PARAMETER gradients only
+    (``torch.autograd.backward(d_loss, inputs=d.parameters())``).  ``needs_input_grad`` of the first layers still says
+    "the images want a gradient" (they did, for the R1 pass), so without this hint the final backward of the D phase would
+    push the gradient all the way down to the images -- an input-gradient convolution at the full resolution for
+    both halves of the batch, thrown away.  Layers whose input is pure DATA (a leaf that is not a parameter, or something
+    computed from such leaves without any parameter: ``mark_data``) skip their input gradient inside this context."""
+    prev = _ParamsOnly.active
+    _ParamsOnly.active = True
+    try:
+        yield
+    finally:
+        _ParamsOnly.active = prev
+
+
+def is_data(x):
+    """Is ``x`` (tensor or Pair) free of parameters upstream, as far as this module can tell?"""
+    if isinstance(x, Pair):
+        return is_data(x.r) and is_data(x.f)
+    if x is None:
+        return True
+    return bool(getattr(x, '_tg_data', False)) or (x.is_leaf and not isinstance(x, torch.nn.Parameter))
+
+
+def mark_data(out, *sources):
+    """Tag ``out`` (tensor / Pair / tuple of them) as data when every source is."""
+    if all(is_data(s) for s in sources):
+        for o in (out if isinstance(out, tuple) else (out,)):
+            for t in ((o.r, o.f) if isinstance(o, Pair) else (o,)):
+                t._tg_data = True
+    return out
+
+
+def _skip_input_grad(ctx):
+    return _ParamsOnly.active and getattr(ctx, 'data_input', False)
+
+
 # =========================================================================== real | fake pairs
 class Pair:
     """The real and the fake batch of a discriminator step travelling through the network as ONE tensor of 2B images.
@@ -266,6 +308,10 @@ class _Paired(Function):
         ctx.save_for_backward(*rec.saved_tensors, *reals)
         ctx.F, ctx.kinds, ctx.materialize = F, kinds, rec.materialize
         ctx.attrs = {k: v for k, v in vars(rec).items() if k not in ('saved_tensors', 'materialize', 'needs_input_grad')}
+        if 'data_input' in ctx.attrs:
+            first = layout.index('b')
+            pos0 = sum(2 if k == 'b' else 1 for k in layout[:first])
+            ctx.attrs['data_input'] = is_data(args[pos0]) and is_data(args[pos0 + 1])
         ctx.set_materialize_grads(False)
         flat = []
         for kind, o in zip(kinds, outs):
@@ -409,6 +455,7 @@ class _ConvFwd(Function):
         ctx.save_for_backward(x, w, bias)
         ctx.has_residual = residual is not None
         ctx.residual_up = residual_up
+        ctx.data_input = is_data(x)          # (under _Paired: overwritten from the original halves)
         return y
 
     @staticmethod
@@ -418,7 +465,7 @@ class _ConvFwd(Function):
         gx = gw = gb = None
         need_w = ctx.needs_input_grad[1] and _param_grads_wanted()
         need_b = bias is not None and ctx.needs_input_grad[2] and _param_grads_wanted()
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not _skip_input_grad(ctx):
             gx = _ConvDgrad.apply(gy, w)
         sink_w, sink_b = _grad_sink(w), _grad_sink(bias)
         if need_w and sink_w is not None and (not need_b or sink_b is not None):
@@ -746,6 +793,11 @@ class _PoolConv(Function):
         gx = gw = gb = None
         need_w = need[1] and _param_grads_wanted()
         need_b = bias is not None and need[2] and _param_grads_wanted()
+        gres = gy if ctx.has_residual and need[3] else None
+        if need[0] and gres is not None and torch.is_grad_enabled() and gy.requires_grad:
+            # R1 first-order pass (create_graph): gy feeds the transposed conv AND the shortcut -- one node for both uses, so
+            # that the second-order sweep adds their two adjoints in one kernel instead of an autograd add
+            gy, gres = _ForkN.apply(gy, 2)
         if need[0]:
             gx = _PoolConvT.apply(gy, w)
         if need_w:
@@ -768,7 +820,7 @@ class _PoolConv(Function):
                 K().channel_sum(gy, sink_b, _ws(gy, K().bn_workspace(Bn, Cn, hw)), Bn, Cn, hw, 1)
             else:
                 gb = _ChannelSum.apply(gy)
-        return gx, gw, gb, (gy if ctx.has_residual and need[3] else None)
+        return gx, gw, gb, gres
 
 
 class _PoolConvT(Function):
@@ -1281,8 +1333,8 @@ def fork_upsample_nearest2x(x):
 def bilinear_half(x):
     """F.interpolate(x, scale_factor=0.5, mode='bilinear', align_corners=True)"""
     if _is_pair(x):
-        return pair_apply(_BilinearHalf, x)
-    return _BilinearHalf.apply(x)
+        return mark_data(pair_apply(_BilinearHalf, x), x)
+    return mark_data(_BilinearHalf.apply(x), x)
 
 
 PAIR_SPECS[_BilinearHalf] = ('b', '', 'b')
@@ -1370,8 +1422,8 @@ class _CopyChannels(Function):
 
 def copy_channels(x, channels, fill=0.0):
     if _is_pair(x):
-        return pair_apply(_CopyChannels, x, channels, fill)
-    return _CopyChannels.apply(x, channels, fill)
+        return mark_data(pair_apply(_CopyChannels, x, channels, fill), x)
+    return mark_data(_CopyChannels.apply(x, channels, fill), x)
 
 
 PAIR_SPECS[_CopyChannels] = ('b--', '', 'b')
@@ -1531,8 +1583,8 @@ class _ForkN(Function):
 def fork(x, n):
     """-> n tensors equal to x whose gradients are summed by one kernel (2 <= n <= 4)."""
     if _is_pair(x):
-        return pair_apply(_ForkN, x, n)
-    return _ForkN.apply(x, n)
+        return mark_data(pair_apply(_ForkN, x, n), x)
+    return mark_data(_ForkN.apply(x, n), x)
 
 
 PAIR_SPECS[_ForkN] = ('b-', '', '*')

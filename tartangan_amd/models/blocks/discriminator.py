@@ -85,8 +85,11 @@ class ResidualDiscriminatorBlock(nn.Module):
         Cout = conv1.weight.shape[0]
         w1 = torch.cat([rgb_conv.weight.view(C, Cimg), rgb_conv.bias.view(C, 1)], 1)                  # (C, Cimg + 1)
         wc = TF.matmul(w1.unsqueeze(0).expand(Cout, C, Cimg + 1), conv1.weight.view(Cout, C, 9), transA=True)
-        h = TF.conv2d(TF.copy_channels(img, Cimg + 1, 1.0), wc.view(Cout, Cimg + 1, 3, 3), conv1.bias)     # [img, 1] in one pass
-        shortcut = run_layers(rgb.convs, self.interpolate(img))
+        img_a = img_b = img
+        if img.requires_grad and torch.is_grad_enabled():
+            img_a, img_b = TF.fork(img, 2)         # two consumers (R1 differentiates w.r.t. the images): one fan-in kernel
+        h = TF.conv2d(TF.copy_channels(img_a, Cimg + 1, 1.0), wc.view(Cout, Cimg + 1, 3, 3), conv1.bias)     # [img, 1] in one pass
+        shortcut = run_layers(rgb.convs, self.interpolate(img_b))
         return run_layers(self.convs[1:], h, residual=shortcut)
 
 

@@ -126,8 +126,7 @@ class CNNTrainer(Trainer):
         toggle_grad(self.d, True)
         self.optimizer_d.zero_grad()
         fake = self.sample_g(bs)
-        labels = torch.zeros(2 * bs, 1, device=self.device)
-        labels[:bs] = 1
+        labels = self._labels(bs)
         fake = fake.detach()
         if self._d_pairable() and fake.shape == imgs.shape:
             # real | fake back to back in ONE buffer: every paired op then sees its input as an alias, not a copy
@@ -146,9 +145,20 @@ class CNNTrainer(Trainer):
                 d_loss = TF.add(d_loss, d_grad_penalty)
             # same parameter gradients as d_loss.backward(); naming the leaves just spares autograd the gradient
             # w.r.t. the real images, which the reference computes (real.requires_grad_) and never reads
-            with TF.deferred_wgrad():       # one launch finishes all conv weight-gradient reductions of this pass
+            with TF.deferred_wgrad(), TF.params_only():     # one launch finishes all conv weight-gradient reductions of this pass
                 torch.autograd.backward(d_loss, inputs=[p for p in self.d.parameters() if p.requires_grad])
         return d_loss.detach(), (d_grad_penalty.detach() if d_grad_penalty is not None else None)
+
+    def _labels(self, bs):
+        """(2 bs, 1): ones for the real half, zeros for the fake half (cnn.py:118-121); its first half doubles as the
+        all-ones target of the generator phase (:146).  Constant per batch size: built once, not refilled every step."""
+        cache = self.__dict__.setdefault('_label_cache', {})
+        key = (bs, str(self.device))
+        if key not in cache:
+            labels = torch.zeros(2 * bs, 1, device=self.device)
+            labels[:bs] = 1
+            cache[key] = labels
+        return cache[key]
 
     def _g_forward(self, bs):
         """First part of the generator half (cnn.py:139-143): the generator's forward pass.  It reads no discriminator
@@ -162,7 +172,7 @@ class CNNTrainer(Trainer):
     def _g_backward(self, fake):
         """Second part (cnn.py:144-148): D(fake) with the stepped discriminator, the loss, g_loss.backward()."""
         with TF.filter_forms():
-            g_loss = self._g_loss(fake, torch.ones(len(fake), 1, device=self.device))
+            g_loss = self._g_loss(fake, self._labels(len(fake))[:len(fake)])
             with TF.deferred_wgrad():
                 g_loss.backward()
         return g_loss.detach()

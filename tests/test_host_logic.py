@@ -433,3 +433,43 @@ def test_paired_pass_runs_the_r1_penalty_on_the_real_half_only():
         backend._set_backend_for_testing(prev)
     sizes = {k: sorted({b for kk, b in calls if kk == k}) for k in ('fwd', 'dgrad')}
     assert sizes['fwd'] == [4, 8] and sizes['dgrad'] == [4, 8], sizes        # 4: generator + R1 passes; 8: the paired D passes
+
+
+def test_final_d_backward_skips_the_input_gradient_of_the_first_layers():
+    """``params_only``: the final backward of the D phase asks for parameter gradients only; the from-RGB layers (whose
+    input is pure data) must not run their input-gradient convolutions there -- the R1 first-order pass (needs d/d real) and
+    the generator phase (needs d/d fake) still do.  Same gradients either way."""
+    cfg = GAN_CONFIGS['32']._replace(attention=())
+    calls = []
+
+    class Counting(Emulator):
+        def conv2d_dgrad(self, gy, w, gx, B, Cin, Cout, H, W, ks):
+            calls.append((B, Cin, Cout, H, ks))
+            return super().conv2d_dgrad(gy, w, gx, B, Cin, Cout, H, W, ks)
+
+    prev = backend._set_backend_for_testing(Counting())
+    try:
+        grads = []
+        for hint in (True, False):
+            tr = CNNTrainer(CNNTrainer.default_args(config=cfg, batch_size=4, device='cpu'))
+            torch.manual_seed(0)
+            tr.build_models()
+            calls.clear()
+            orig = TF.params_only
+            if not hint:
+                TF.params_only = contextlib.nullcontext
+            try:
+                torch.manual_seed(1)
+                tr._d_phase(synthetic_images(4, 32, 1))
+            finally:
+                TF.params_only = orig
+            first = [c for c in calls if c[3] == 32 and c[1] in (3, 4)]       # input gradients w.r.t. [img, 1] / img at 32 x 32
+            assert sorted(c[0] for c in first) == ([4] if hint else [4, 8]), first     # R1 pass only / + the wasted 2B one
+            grads.append(tr.optimizer_d.grads.clone())
+            if hint:
+                calls.clear()
+                tr._g_phase(4)
+                assert any(c[3] == 32 and c[1] in (3, 4) for c in calls)          # the G phase needs d/d fake
+        assert torch.equal(grads[0], grads[1])
+    finally:
+        backend._set_backend_for_testing(prev)

@@ -8,7 +8,7 @@ torch.set_num_threads(8)
 for case in sys.argv[1:]:
     fx = load_golden(case)
     vals = []
-    for trial in range(6):
+    for trial in range(int(__import__("os").environ.get("KNIFE_TRIALS", "6"))):
         flags = dict(fx.get('flags', {})); flags.pop('model_scale', None)
         torch.manual_seed(0)
         tr = O.OracleTrainer(fx['config'], fx['trainer'], fx['batch'], attention=fx['attention'], blocks=fx.get('blocks'), latent_dims=fx.get('latent_dims'), **flags)
