@@ -40,16 +40,37 @@ def pack(tensors, like):
     return flat
 
 
+def _param_list(module):
+    """``list(module.parameters())``, cached on the module: the recursive walk costs ~100 us for these networks, and a
+    replayed step checks its bindings several times."""
+    cached = module.__dict__.get('_tg_params')
+    key = (len(module._modules), len(module._parameters))
+    if cached is not None and cached[0] == key and cached[2][0] < 64:
+        cached[2][0] += 1
+        return cached[1]
+    # (a Parameter OBJECT replaced deep inside the tree -- ``setattr(m, 'weight', new)``; ``module.to()`` and
+    # ``load_state_dict`` keep the objects -- is noticed at the latest after 64 uses, when the walk is taken again)
+    params = list(module.parameters())
+    module.__dict__['_tg_params'] = (key, params, [0])
+    return params
+
+
+def invalidate_param_cache(module):
+    module.__dict__.pop('_tg_params', None)
+
+
 def flatten_parameters(module):
     """Re-home ``module``'s parameters into one flat buffer; returns (flat_params, flat_grads).
 
     Parameter objects are preserved (same identity, order, names, state_dict keys);
     ``load_state_dict`` / in-place updates keep working because they copy into the views.
     """
-    params = [p for p in module.parameters()]
+    params = _param_list(module)
     cached = getattr(module, '_tg_flat', None)
     if cached is not None and _is_bound(params, *cached):
         return cached
+    invalidate_param_cache(module)                 # about to rebuild: take a fresh walk of the module tree
+    params = _param_list(module)
     # first call, or the binding was broken from outside: module.to(), zero_grad(set_to_none=True), p.grad = None,
     # torch.save(module) / torch.load (the reference's ModelCheckpoint pickles whole models,
     # components/model_checkpoint.py:35-45) all leave parameters that are no longer views of the buckets.
@@ -137,9 +158,11 @@ class FusedAdam:
         self.ensure_bound()
         _be.get().fill(self.grads, 0.0, self.grads.numel())
 
-    def advance(self):
-        """Host half of a step: bump the step index and upload its scalars (not capturable)."""
-        self.ensure_bound()
+    def advance(self, checked=False):
+        """Host half of a step: bump the step index and upload its scalars (not capturable).  ``checked``: the caller has
+        just run ``ensure_bound()`` itself."""
+        if not checked:
+            self.ensure_bound()
         self.step_count += 1
         b1, b2 = self.betas
         bc1 = 1 - b1 ** self.step_count

@@ -183,8 +183,7 @@ class CNNTrainer(Trainer):
 
     def train_batch(self, imgs):
         imgs = imgs.to(self.device)
-        self.g.train()
-        self.d.train()
+        self._training_mode()
         dp = self.data_parallel
         graphs_ok = dp is None or dp.capturable      # SyncBN over gloo: host-side collectives inside the passes
         self._in_step = True
@@ -198,6 +197,19 @@ class CNNTrainer(Trainer):
         self.steps += 1
         vals = torch.stack([v for v in vals if v is not None]).tolist()     # one device->host read
         return dict(g_loss=vals[0], d_loss=vals[1], gp=vals[2] if len(vals) > 2 else 0.)
+
+    def _training_mode(self):
+        """``self.g.train(); self.d.train()`` (cnn.py:110-111) -- as a check over a cached module list when nothing has to
+        change: the recursive ``train()`` walks ~250 modules and costs the replayed step ~150 us of host time in which the
+        GPU idles; reading 250 flags costs ~10."""
+        cache = self.__dict__.get('_mode_cache')
+        if cache is None or cache[0] is not self.g or cache[1] is not self.d:
+            cache = (self.g, self.d, list(self.g.modules()) + list(self.d.modules()))
+            self._mode_cache = cache
+        if not all(m.training for m in cache[2]):
+            self.g.train()
+            self.d.train()
+            self._mode_cache = None          # (a module added since the list was taken is picked up by the next walk)
 
     def _train_batch_eager(self, imgs):
         d_loss, d_grad_penalty = self._d_phase(imgs)
@@ -300,8 +312,8 @@ class CNNTrainer(Trainer):
                     feed.mode = 'off'
         g1, g2a, g2b, g3 = self._graphs
         self._static_imgs.copy_(imgs, non_blocking=True)
-        self.optimizer_d.advance()
-        self.optimizer_g.advance()
+        self.optimizer_d.advance(checked=True)
+        self.optimizer_g.advance(checked=True)
         g1.replay()
         self._begin_reduce('d', self.optimizer_d)
         if g2a is not None:
