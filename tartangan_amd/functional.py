@@ -271,16 +271,17 @@ class _Paired(Function):
     forward : the halves are joined (an alias, see ``_join``), ``F.forward`` runs ONCE on 2B images, the outputs are handed
               back as two views.  Autograd sees one node with inputs (.., x_r, x_f, ..) and outputs (y_r, y_f).
     backward: gradients for BOTH halves (the final backward of the D phase) -> joined, ``F.backward`` runs once on 2B;
-              a gradient for the REAL half only (the R1 penalty's ``autograd.grad(p_real.sum(), real, create_graph=True)``)
-              -> ``F.backward`` runs on the real-half views of the saved tensors, building exactly the graph the unpaired
-              real pass would build (B images; its second-order sweep is untouched).
+              a gradient for ONE half only (the R1 penalty's ``autograd.grad(p_real.sum(), real, create_graph=True)``
+              reaches the real half alone; of the generator's two forwards of a step only the G phase's is
+              differentiated) -> ``F.backward`` runs on that half's views of the saved tensors, building exactly the
+              graph the unpaired pass would build (B images; the R1 second-order sweep is untouched).
     ``F``'s own forward / backward are reused unchanged through a stand-in ctx (``_PairCtx``)."""
     handles_none_grads = True
 
     @staticmethod
     def forward(ctx, F, *args):
         layout, _, out_spec = PAIR_SPECS[F]
-        fargs, pos, reals, joined = [], 0, [], {}
+        fargs, pos, reals, fakes, joined = [], 0, [], [], {}
         for kind in layout:
             if kind == 'b':
                 r, f = args[pos], args[pos + 1]
@@ -292,6 +293,7 @@ class _Paired(Function):
                     fargs.append(both)
                     joined[id(both)] = len(reals)
                     reals.append(r)
+                    fakes.append(f)
             else:
                 fargs.append(args[pos])
                 pos += 1
@@ -305,7 +307,8 @@ class _Paired(Function):
         # ``F.backward`` the ORIGINAL real input (a saved input is re-attached to the graph when unpacked; the joined alias
         # made in here has no history), or the R1 penalty's second derivative through that input would be lost.
         ctx.from_input = [None if t is None else joined.get(id(t)) for t in rec.saved_tensors]
-        ctx.save_for_backward(*rec.saved_tensors, *reals)
+        ctx.n_halves = len(reals)
+        ctx.save_for_backward(*rec.saved_tensors, *reals, *fakes)
         ctx.F, ctx.kinds, ctx.materialize = F, kinds, rec.materialize
         ctx.attrs = {k: v for k, v in vars(rec).items() if k not in ('saved_tensors', 'materialize', 'needs_input_grad')}
         if 'data_input' in ctx.attrs:
@@ -338,20 +341,25 @@ class _Paired(Function):
             else:
                 groups.append((kind, gouts[pos], None, pos))
                 pos += 1
-        half = all(gf is None for kind, _, gf, _ in groups if kind == 'b') and any(kind == 'b' for kind, *_ in groups)
+        has_b = any(kind == 'b' for kind, *_ in groups)
+        half = has_b and all(gf is None for kind, _, gf, _ in groups if kind == 'b')          # the first half alone
+        half_f = has_b and not half and all(g is None for kind, g, _, _ in groups if kind == 'b')   # the second half alone
         need = ctx.needs_input_grad
         sub = _PairCtx()
         sub.__dict__.update(ctx.attrs)
         sub_need, pos = [], 1
         for kind in layout:
             if kind == 'b':
-                sub_need.append(need[pos] if half else (need[pos] or need[pos + 1]))
+                sub_need.append(need[pos] if half else need[pos + 1] if half_f else (need[pos] or need[pos + 1]))
                 pos += 2
             else:
                 sub_need.append(need[pos])
                 pos += 1
         sub.needs_input_grad = tuple(sub_need)
-        saved, reals = ctx.saved_tensors[:len(ctx.from_input)], ctx.saved_tensors[len(ctx.from_input):]
+        n_saved = len(ctx.from_input)
+        saved = ctx.saved_tensors[:n_saved]
+        reals = ctx.saved_tensors[n_saved:n_saved + ctx.n_halves]
+        fakes = ctx.saved_tensors[n_saved + ctx.n_halves:]
         device = next(g for g in gouts if g is not None).device
 
         def zeros(at):
@@ -359,13 +367,19 @@ class _Paired(Function):
             return torch.zeros(shape, dtype=dtype, device=device)
 
         gin = []
-        if half:
-            sub.saved_tensors = tuple(reals[j] if j is not None else (t[:t.shape[0] // 2] if (k == 'h' and t is not None) else t)
+        if half or half_f:
+            own = reals if half else fakes
+
+            def view(t):                    # this half's rows of a saved tensor (statistics: this group's entries)
+                n = t.shape[0] // 2
+                return t[:n] if half else t[n:]
+            sub.saved_tensors = tuple(own[j] if j is not None else (view(t) if (k == 'h' and t is not None) else t)
                                       for k, t, j in zip(saved_spec, saved, ctx.from_input))
             if hasattr(F, 'pair_half'):
                 F.pair_half(sub)
-            for kind, g, _, at in groups:
-                gin.append(zeros(at) if (g is None and ctx.materialize) else g)
+            for kind, g, gf, at in groups:
+                g = g if (half or kind != 'b') else gf
+                gin.append(zeros(at + (1 if (half_f and kind == 'b') else 0)) if (g is None and ctx.materialize) else g)
         else:
             sub.saved_tensors = saved
             for kind, g, gf, at in groups:
@@ -388,6 +402,8 @@ class _Paired(Function):
                 out += [None, None]
             elif half:
                 out += [g, None]
+            elif half_f:
+                out += [None, g]
             else:
                 n = g.shape[0] // 2
                 out += [g[:n], g[n:]]
@@ -730,7 +746,12 @@ def upconv3x3_pays(a, weight):
 
 def upconv3x3(a, weight, bias=None, residual=None):
     """conv2d(F.interpolate(a, scale_factor=2), weight, bias, padding=1) [+ residual]"""
+    if _is_pair(a):
+        return pair_apply(_UpConv3x3, a, weight, bias, residual)
     return _UpConv3x3.apply(a, weight, bias, residual)
+
+
+PAIR_SPECS[_UpConv3x3] = ('b--b', 'h--', 'b')
 
 
 class _FilterForms:
@@ -1223,7 +1244,12 @@ class _Pool2(Function):
 
 
 def upsample_nearest2x(x):
+    if _is_pair(x):
+        return pair_apply(_Up2x, x, 1.0)
     return _Up2x.apply(x, 1.0)
+
+
+PAIR_SPECS[_Up2x] = ('b-', '', 'b')
 
 
 def avg_pool2(x, residual=None):
@@ -1327,7 +1353,12 @@ PAIR_SPECS[_ForkBilinearHalf] = ('b', '', 'bb')
 
 def fork_upsample_nearest2x(x):
     """-> (up, up) with up = F.interpolate(x, scale_factor=2), for two consumers"""
+    if _is_pair(x):
+        return pair_apply(_ForkUp2x, x)
     return _ForkUp2x.apply(x)
+
+
+PAIR_SPECS[_ForkUp2x] = ('b', '', 'bb')
 
 
 def bilinear_half(x):
@@ -1875,7 +1906,12 @@ class _TanhBwd(Function):
 
 
 def tanh(x):
+    if _is_pair(x):
+        return pair_apply(_Tanh, x)
     return _Tanh.apply(x)
+
+
+PAIR_SPECS[_Tanh] = ('b', 'h', 'b')
 
 
 # =========================================================================== softmax

@@ -128,6 +128,7 @@ class FusedAdam:
         self._hyper_host = torch.zeros(6, dtype=torch.float32)
         if self.flat.is_cuda:
             self._hyper_host = self._hyper_host.pin_memory()
+        self._hyper_np = self._hyper_host.numpy()            # (one vectorised host write per step instead of six tensor setitems)
 
     def ensure_bound(self):
         """Re-home the parameters if something outside detached them from the buckets (see flatten_parameters); without
@@ -146,6 +147,7 @@ class FusedAdam:
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop('_hyper_host', None)       # pinned host memory does not pickle as pinned; rebuilt on load
+        state.pop('_hyper_np', None)
         state.pop('_hyper', None)
         return state
 
@@ -167,9 +169,8 @@ class FusedAdam:
         b1, b2 = self.betas
         bc1 = 1 - b1 ** self.step_count
         bc2 = 1 - b2 ** self.step_count
-        h = self._hyper_host
-        h[0], h[1], h[2], h[3], h[4], h[5] = self.lr / bc1, math.sqrt(bc2), b1, b2, 1 - b1, 1 - b2
-        self._hyper.copy_(h, non_blocking=True)
+        self._hyper_np[:] = (self.lr / bc1, math.sqrt(bc2), b1, b2, 1 - b1, 1 - b2)
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
 
     def apply(self):
         """Device half of a step: one kernel over the flat buffer (capturable)."""

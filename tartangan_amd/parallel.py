@@ -55,8 +55,6 @@ class DataParallel:
         feed = trainer.rng_feed
         feed.rank, feed.world = self.rank, self.world
         trainer._route_rng_through_feed()       # IQN taus must come through the feed to be sliced per rank
-        if not getattr(trainer, '_graph_requested', False):
-            feed.mode = 'off'                   # eager: draw (and slice) the global tensors on every call
         self.bn_group = None
         if self.sync_bn and self.world > 1:
             # SyncBN's collectives sit INSIDE the passes (with RCCL: captured into the step's graphs) while a gradient bucket

@@ -122,10 +122,14 @@ class CNNTrainer(Trainer):
         """Discriminator half up to and including d_loss.backward() (cnn.py:112-136).
         Returns (d_loss, d_grad_penalty or None) as device tensors."""
         bs = len(imgs)
+        both_fakes = self._generator_forward_for_both_phases(bs)
         toggle_grad(self.g, False)
         toggle_grad(self.d, True)
         self.optimizer_d.zero_grad()
-        fake = self.sample_g(bs)
+        if both_fakes is None:
+            fake = self.sample_g(bs)
+        else:
+            fake, self._fake_for_g_phase = both_fakes
         labels = self._labels(bs)
         fake = fake.detach()
         if self._d_pairable() and fake.shape == imgs.shape:
@@ -167,7 +171,59 @@ class CNNTrainer(Trainer):
         toggle_grad(self.g, True)
         toggle_grad(self.d, False)
         self.optimizer_g.zero_grad()
+        fake = self.__dict__.pop('_fake_for_g_phase', None)
+        if fake is not None:
+            self.sample_z(bs)          # this phase's latent in the step's RNG plan: the paired forward of the D phase used it
+            return fake
         return self.sample_g(bs)
+
+    def _generator_forward_for_both_phases(self, bs):
+        """The generator runs twice per step with the SAME weights -- ``sample_g`` of the D phase (cnn.py:117, no gradient)
+        and of the G phase (:143) -- on different latents.  When the step's random inputs are pre-drawn (``RngFeed`` serving
+        a recorded plan: every step but the first) both latents exist up front, and the two forwards run as ONE pass over
+        2B latents (``functional.Pair``: BatchNorm statistics per half, running statistics updated D-phase half first).
+        -> (fake for the D phase (detached), fake for the G phase (with its graph)) or None."""
+        feed = self.rng_feed
+        if not (self._in_step and feed.mode == 'serve' and self._g_pairable()):
+            return None
+        i = feed.cursor
+        later = [k for k in range(i + 1, len(feed.plan)) if feed.plan[k][0] == 'z']
+        if i >= len(feed.plan) or feed.plan[i] != ('z', bs, self.gan_config.latent_dims) or not later or feed.plan[later[0]] != feed.plan[i]:
+            return None
+        z_d = self.sample_z(bs)
+        z_g = feed.static[later[0]]              # (its plan entry is consumed by the G phase, see _g_forward)
+        toggle_grad(self.g, True)                # the G-phase half needs its graph; the D-phase half is detached below
+        out = self.g(TF.Pair(z_d, z_g))
+        return out.r.detach(), out.f
+
+    def _rng_plan(self, bs):
+        """Random inputs of one step in draw order: the D phase's latents, the G phase's latents (trainer.py:153-156)."""
+        z = ('z', bs, self.gan_config.latent_dims)
+        return [z, z]
+
+    def _known_rng_plan(self, bs):
+        """``_rng_plan`` when this is a stock trainer on stock models (the draw order is then this package's own);
+        otherwise None: the first step records what is drawn."""
+        from .iqn import IQNTrainer
+        if type(self) not in (CNNTrainer, IQNTrainer) or type(self.g) is not Generator or type(self.d) is not self.discriminator_class:
+            return None
+        return self._rng_plan(bs)
+
+    def _g_pairable(self):
+        if not getattr(self.args, 'pair_g', True):
+            return False
+        cached = self.__dict__.get('_pair_g_ok')
+        key = (id(self.g), self.data_parallel is not None and self.data_parallel.sync_bn)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        ok = isinstance(self.g.blocks[0], GeneratorInputMLP)
+        for m in self.g.modules():
+            if not (type(m).__module__.startswith('tartangan_amd.') or type(m) in (nn.Sequential, nn.Identity, nn.ModuleList)):
+                ok = False
+            if isinstance(m, BatchNorm2d) and m.sync_group is not None:
+                ok = False
+        self._pair_g_ok = (key, ok)
+        return ok
 
     def _g_backward(self, fake):
         """Second part (cnn.py:144-148): D(fake) with the stepped discriminator, the loss, g_loss.backward()."""
@@ -186,6 +242,26 @@ class CNNTrainer(Trainer):
         self._training_mode()
         dp = self.data_parallel
         graphs_ok = dp is None or dp.capturable      # SyncBN over gloo: host-side collectives inside the passes
+        # The step's random inputs (latents, IQN quantile fractions) go through RngFeed: the FIRST step draws them inline,
+        # in the reference's order, and records that order; every later step of the same batch shape draws them all up
+        # front in the recorded order (same stream: nothing else draws inside a step) -- which is what lets a step replay
+        # from HIP graphs and lets the generator's two forwards share one pass.  Another batch shape (a ragged last
+        # batch): plain inline draws for that call.
+        feed = self.rng_feed
+        self._route_rng_through_feed()
+        shape, restore = tuple(imgs.shape), None
+        if not feed.plan:
+            known = self._known_rng_plan(len(imgs))
+            if known is not None:
+                feed.adopt(known)         # the stock step's draw order is known in advance: no recording step
+        if not feed.plan:
+            feed.mode, feed.key = 'record', shape
+        elif feed.key is None or feed.key == shape:
+            feed.key = shape
+            feed.mode = 'serve'
+            feed.refill()
+        else:
+            restore, feed.mode = feed.mode, 'off'
         self._in_step = True
         try:
             if graphs_ok and (getattr(self, '_graphs', None) is not None or getattr(self, '_graph_requested', False)):
@@ -194,9 +270,25 @@ class CNNTrainer(Trainer):
                 vals = self._train_batch_eager(imgs)
         finally:
             self._in_step = False
+            self.__dict__.pop('_fake_for_g_phase', None)
+            if restore is not None:
+                feed.mode = restore
         self.steps += 1
-        vals = torch.stack([v for v in vals if v is not None]).tolist()     # one device->host read
+        if not torch.is_tensor(vals):
+            vals = torch.stack([v for v in vals if v is not None])
+        vals = self._read_back(vals)                                         # one device->host read
         return dict(g_loss=vals[0], d_loss=vals[1], gp=vals[2] if len(vals) > 2 else 0.)
+
+    def _read_back(self, vals):
+        """The step's three losses as Python floats (the reference's ``float(g_loss)`` ...: its one host sync per step)."""
+        if not vals.is_cuda:
+            return vals.tolist()
+        host = self.__dict__.get('_loss_host')
+        if host is None or host.numel() != vals.numel():
+            host = self._loss_host = torch.empty(vals.numel(), dtype=torch.float32).pin_memory()
+        host.copy_(vals, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return host.tolist()
 
     def _training_mode(self):
         """``self.g.train(); self.d.train()`` (cnn.py:110-111) -- as a check over a cached module list when nothing has to
@@ -235,18 +327,14 @@ class CNNTrainer(Trainer):
             raise RuntimeError('HIP graphs need a ROCm device')
         self._graph_requested = True
         self._graphs = None
-        self._route_rng_through_feed()
 
     def _route_rng_through_feed(self):
-        if self.rng_feed.mode == 'off':
-            self.rng_feed.mode = 'record'
         iqn = getattr(getattr(self.d, 'to_output', None), 'iqn', None)
-        if iqn is not None:
+        if iqn is not None and iqn.tau_source is None:
             iqn.tau_source = lambda rows, q: self._draw('tau', rows, q)
 
     def _capture(self, imgs):
         feed = self.rng_feed
-        feed.mode = 'serve'
         feed.cursor = 0
         self._static_imgs = imgs.clone()
         torch.cuda.synchronize()
@@ -273,25 +361,20 @@ class CNNTrainer(Trainer):
         with torch.cuda.graph(g3, **kw):
             self.optimizer_g.apply()
             self.update_target_generator()
+            # the losses side by side in one static buffer: the replayed step reads back ONE tensor, no launch of its own
+            self._out_losses = torch.stack([v for v in (self._out_g, self._out_d[0], self._out_d[1]) if v is not None])
         self._graphs = (g1, g2a, g2b, g3)
         feed.cursor = 0
 
     def _train_batch_graphed(self, imgs):
         feed = self.rng_feed
-        if self._graphs is None and not feed.plan:
-            return self._train_batch_eager(imgs)               # call 1: eager, records the RNG plan
+        if feed.mode != 'serve':
+            # call 1 (the RNG plan is being recorded), or a batch of another shape than the plan / the captured graphs
+            # (a ragged last batch): this call runs eagerly
+            return self._train_batch_eager(imgs)
         gen = (self.optimizer_d.ensure_bound(), self.optimizer_g.ensure_bound())
-        if self._graphs is not None and (gen != self._graph_gen or imgs.shape != self._static_imgs.shape):
-            if imgs.shape != self._static_imgs.shape:
-                # a ragged last batch: the captured graphs are for one batch shape; run this call eagerly
-                # (the RNG plan is per shape too, so draw directly)
-                mode, feed.mode = feed.mode, 'off'
-                try:
-                    return self._train_batch_eager(imgs)
-                finally:
-                    feed.mode = mode
+        if self._graphs is not None and gen != self._graph_gen:
             self._graphs = None                                # parameter buckets were rebuilt: recapture
-        feed.refill()
         if self._graphs is None:                               # call 2: capture (nothing executes yet)
             try:
                 self._capture(imgs)
@@ -305,11 +388,9 @@ class CNNTrainer(Trainer):
                 warnings.warn(f'HIP-graph capture failed ({exc!r}); continuing in eager mode')
                 self._graph_requested = False
                 self._graphs = None
-                feed.mode, feed.cursor = 'serve', 0
-                try:
-                    return self._train_batch_eager(imgs)       # consumes the values refill() just drew
-                finally:
-                    feed.mode = 'off'
+                feed.cursor = 0
+                self.__dict__.pop('_fake_for_g_phase', None)
+                return self._train_batch_eager(imgs)           # consumes the values refill() drew for this step
         g1, g2a, g2b, g3 = self._graphs
         self._static_imgs.copy_(imgs, non_blocking=True)
         self.optimizer_d.advance(checked=True)
@@ -323,7 +404,7 @@ class CNNTrainer(Trainer):
         self._begin_reduce('g', self.optimizer_g)
         self._finish_reduce('g')
         g3.replay()
-        return self._out_g, self._out_d[0], self._out_d[1]
+        return self._out_losses
 
     def _begin_reduce(self, key, optimizer):
         """Data-parallel hooks: start / join the averaging of a flat gradient bucket over the ranks (no-ops on 1 GPU)."""

@@ -25,6 +25,13 @@ class IQNTrainer(CNNTrainer):
         _, loss_fake = self.d(fake, targets=labels[bs:])           # ... then here (8B)
         return p_real, TF.add(loss_real, loss_fake)
 
+    def _rng_plan(self, bs):
+        """z; taus of D(real), D(fake) (models/iqn.py:105-108 inside each head evaluation); z; taus of the G phase's D(fake)."""
+        z = ('z', bs, self.gan_config.latent_dims)
+        q = self.d.to_output.iqn.num_quantiles
+        t = ('tau', q * bs, q)
+        return [z, t, t, z, t]
+
     def _g_loss(self, fake, ones):
         _, g_loss = self.d(fake, targets=ones)
         return g_loss

@@ -34,6 +34,7 @@ class RngFeed:
         self.host = []
         self.mode = 'record'
         self.cursor = 0
+        self.key = None         # batch shape the plan was recorded for
 
     def _draw_cpu(self, kind, rows, cols):
         if kind == 'z':
@@ -62,9 +63,27 @@ class RngFeed:
         self.cursor += 1
         return buf
 
+    def adopt(self, plan):
+        """Start from a plan that is known in advance (the stock trainers' own draw order) instead of recording it during a
+        first inline-drawing step: every step, the first included, then has the same structure."""
+        self.plan, self.static, self.host = [], [], []
+        for kind, rows, cols in plan:
+            width = cols if kind == 'z' else 1
+            buf = torch.empty(rows, width, dtype=torch.float32, device=self.device)
+            host = torch.empty(rows, width, dtype=torch.float32)
+            self.plan.append((kind, rows, cols))
+            self.static.append(buf)
+            self.host.append(host.pin_memory() if buf.is_cuda else host)
+        self.cursor = 0
+
     def refill(self):
         for (kind, rows, cols), buf, host in zip(self.plan, self.static, self.host):
-            host.copy_(self._draw_cpu(kind, rows, cols))
+            if self.world == 1:
+                # straight into the pinned staging buffer: ``torch.randn(r, c)`` is ``empty(r, c).normal_()`` and
+                # ``torch.rand(r, 1)`` is ``empty(r, 1).uniform_()`` -- the same values from the same generator state
+                host.normal_() if kind == 'z' else host.uniform_()
+            else:
+                host.copy_(self._draw_cpu(kind, rows, cols))
             buf.copy_(host, non_blocking=True)
         self.cursor = 0
 

@@ -473,3 +473,46 @@ def test_final_d_backward_skips_the_input_gradient_of_the_first_layers():
         assert torch.equal(grads[0], grads[1])
     finally:
         backend._set_backend_for_testing(prev)
+
+
+@pytest.mark.parametrize('kind', ['cnn', 'iqn'])
+def test_generator_forwards_of_both_phases_share_one_pass(kind, single_thread):
+    """sample_g of the D phase and of the G phase (same weights, different latents) as ONE pass over 2B latents: same
+    losses / gradients / RNG consumption as two passes, and the generator's BatchNorm buffers see the D-phase half first."""
+    cls = {'cnn': CNNTrainer, 'iqn': IQNTrainer}[kind]
+    cfg = GAN_CONFIGS['32']._replace(attention=(1,))
+    calls = []
+
+    class Counting(Emulator):
+        def conv2d_fwd(self, x, w, bias, residual, y, B, Cin, Cout, H, W, ks):
+            if Cout == 3:
+                calls.append(B)                         # the to-RGB convolution: once per generator pass
+            return super().conv2d_fwd(x, w, bias, residual, y, B, Cin, Cout, H, W, ks)
+
+    prev = backend._set_backend_for_testing(Counting())
+    try:
+        res = []
+        for pair in (True, False):
+            tr = cls(cls.default_args(config=cfg, batch_size=6, device='cpu', pair_g=pair))
+            torch.manual_seed(0)
+            tr.build_models()
+            tr.g.load_state_dict(procedural_state(tr.g.state_dict(), 7))
+            tr.d.load_state_dict(procedural_state(tr.d.state_dict(), 9))
+            calls.clear()
+            torch.manual_seed(5)
+            logs = tr.train_batch(synthetic_images(6, 32, 99))
+            assert calls == ([12] if pair else [6, 6]), calls
+            res.append((logs, {k: v.clone() for k, v in tr.g.state_dict().items()}, float(torch.rand(1))))
+    finally:
+        backend._set_backend_for_testing(prev)
+    (lp, gp_, rp), (ls, gs, rs) = res
+    assert rp == rs
+    for k in lp:
+        assert _close(lp[k], ls[k], 2e-5), (k, lp, ls)
+    for k in gp_:
+        if k.endswith('num_batches_tracked'):
+            assert int(gp_[k]) == int(gs[k]) == 2, k
+        elif k.endswith(('running_mean', 'running_var')):
+            assert torch.allclose(gp_[k], gs[k], rtol=1e-5, atol=1e-6), k
+        else:
+            assert float((gp_[k] - gs[k]).abs().max()) <= 2.1 * 1e-4 + 1e-6, k          # Adam's +-lr sign noise (see above)

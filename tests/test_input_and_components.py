@@ -298,7 +298,6 @@ def test_draws_outside_a_step_bypass_the_recorded_rng_plan(tmp_path, emulated):
     out the step's static buffers and must not be rank-sliced."""
     from tartangan_amd.trainers.components import ImageSamplerComponent
     tr = _trainer(tmp_path)
-    tr._route_rng_through_feed()                      # what enable_graphs() / DataParallel do (record mode)
     sm = ImageSamplerComponent(tr.args)
     tr.attach(sm)
     torch.manual_seed(11)
@@ -313,12 +312,13 @@ def test_draws_outside_a_step_bypass_the_recorded_rng_plan(tmp_path, emulated):
     sm.on_batch_end(0, {})                            # sample_z(4) == the batch size: must not alias the step's z buffer
     assert tr.rng_feed.plan == plan
     assert all(sm._latent_grid_samples.data_ptr() != b.data_ptr() for b in tr.rng_feed.static)
-    tr.rng_feed.mode = 'serve'
-    tr.rng_feed.refill()
-    logs.append(tr.train_batch(imgs))
+    logs.append(tr.train_batch(imgs))                 # (second step: the plan is served, refilled by train_batch itself)
+    assert tr.rng_feed.mode == 'serve'
     after = float(torch.rand(1))
 
-    ref = _trainer(tmp_path)                          # the same run with plain eager draws
+    ref = _trainer(tmp_path)                          # the same run with plain inline draws in every step (no plan, no pairing)
+    ref.args.pair_g = False
+    ref.train_batch = lambda imgs, _tb=ref.train_batch: (ref.rng_feed.plan.clear(), ref.rng_feed.static.clear(), ref.rng_feed.host.clear(), _tb(imgs))[-1]
     sm2 = ImageSamplerComponent(ref.args)
     ref.attach(sm2)
     torch.manual_seed(11)
@@ -327,7 +327,9 @@ def test_draws_outside_a_step_bypass_the_recorded_rng_plan(tmp_path, emulated):
     sm2.on_batch_end(0, {})
     want.append(ref.train_batch(imgs))
     assert float(torch.rand(1)) == after
-    assert logs == want
+    for a, b in zip(logs, want):        # (the second step of the first run shares one generator pass between its phases)
+        # (g_loss is taken after D's Adam step, whose +-lr moves amplify last-bit differences: bounded loosely here)
+        assert all(abs(a[k] - b[k]) <= (1e-3 if k == 'g_loss' else 2e-5) * max(abs(b[k]), 1e-6) for k in b), (a, b)
     assert torch.equal(sm.progress_samples, sm2.progress_samples)
 
 
