@@ -179,7 +179,7 @@ CONV_DIMS = {'conv2d_fwd': slice(5, 11), 'conv2d_dgrad': slice(3, 9), 'conv2d_wg
              'conv2d_wgrad_partials': slice(4, 10)}
 
 
-TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_hbm_traffic.json')
+TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_hbm_traffic.json')
 
 
 def hbm_traffic_per_launch(a):
@@ -200,7 +200,7 @@ def hbm_traffic_per_launch(a):
         blob = subprocess.run(['git', 'hash-object', TRAFFIC_FILE], capture_output=True, text=True, cwd=here).stdout.strip()
     except Exception:
         blob = None
-    prov = {'traffic_source': 'profiles/r02_hbm_traffic.json', 'traffic_file_git_blob': blob or None,
+    prov = {'traffic_source': 'profiles/r03_hbm_traffic.json', 'traffic_file_git_blob': blob or None,
             'traffic_measured_on_conv_hip_sha256': k.get('conv_hip_sha256', '')[:16], 'conv_hip_sha256': sha[:16]}
     if k.get('conv_hip_sha256') != sha:
         prov['traffic_note'] = 'stale: csrc/conv.hip changed since the counters were collected'

@@ -79,7 +79,9 @@ STEP_CONV_SHAPES = [(64, 128, 128, 16, 16, 3), (64, 64, 128, 16, 16, 3), (64, 12
                     (64, 4, 16, 128, 128, 3), (64, 128, 128, 8, 8, 3), (64, 128, 128, 4, 4, 3), (64, 256, 256, 8, 8, 3),
                     # the discriminator's real | fake pass: its forward and final-backward layers at 2 x 64 images
                     (128, 4, 16, 128, 128, 3), (128, 16, 32, 64, 64, 3), (128, 32, 64, 32, 32, 3), (128, 64, 128, 16, 16, 3),
-                    (128, 128, 128, 8, 8, 3)]
+                    (128, 128, 128, 8, 8, 3),
+                    # ... and the generator's forward at 2 x 64 latents (its backward stays at 64)
+                    (128, 128, 128, 16, 16, 3), (128, 64, 64, 32, 32, 3), (128, 32, 32, 64, 64, 3), (128, 16, 16, 128, 128, 3)]
 
 
 def poison_lds(K):
@@ -118,7 +120,9 @@ def test_conv_step_shapes_full_batch_after_lds_poison(K, shape):
 
 STEP_S2_SHAPES = [(64, 128, 128, 8, 8), (64, 128, 64, 16, 16), (64, 64, 32, 32, 32), (64, 32, 16, 64, 64),
                   # pooled convolutions of the paired discriminator pass (2 x 64 images)
-                  (128, 16, 16, 64, 64), (128, 32, 32, 32, 32), (128, 64, 64, 16, 16), (128, 128, 128, 8, 8), (128, 128, 128, 4, 4)]
+                  (128, 16, 16, 64, 64), (128, 32, 32, 32, 32), (128, 64, 64, 16, 16), (128, 128, 128, 8, 8), (128, 128, 128, 4, 4),
+                  # up-convolutions of the generator's shared pass (2 x 64 latents)
+                  (128, 128, 64, 16, 16), (128, 64, 32, 32, 32), (128, 32, 16, 64, 64)]
 
 
 @pytest.mark.parametrize('shape', STEP_S2_SHAPES)

@@ -115,7 +115,8 @@ def test_regular_convs_are_one_trilinear_form_at_full_size(K, step_shapes):
 @pytest.mark.parametrize('form', ['upconv3x3', 'poolconv3x3'])
 def test_stride2_convs_are_one_trilinear_form_at_full_size(K, step_shapes, form):
     shapes = sorted(step_shapes[form + '_fwd'])
-    assert shapes and max(s[0] for s in shapes) == (2 if form == 'poolconv3x3' else 1) * FULL['batch']
+    # (both stride-2 forms run on 2 x batch images: the discriminator's real | fake pass, the generator's two forwards)
+    assert shapes and max(s[0] for s in shapes) == 2 * FULL['batch']
     F = torch.nn.functional
     for (B, Cin, Cout, H, W) in shapes:          # H x W: the low-resolution plane
         w = _rand(Cout, Cin, 3, 3, seed=1, scale=0.1)
