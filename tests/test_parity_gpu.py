@@ -32,7 +32,16 @@ def hip_backend():
 # every D weight moved by lr * sign(gradient), sign decided by rounding where the gradient is ~0 -- moves by up to 6.9e-5 in the
 # reference's own arithmetic under a 1e-7 input perturbation (tools/knife_edge.py, 3 trials, all to the same side); one GPU
 # lands 1.2e-4 away, four ranks with SyncBN (tests/test_dp_gpu.py) within 1e-4.
-KNIFE_EDGE = {'c128a3_iqn_b4': 3e-4, 'c128a3_cnn_b256': 2e-4}
+# c128big_cnn_b8 (1024-channel layers): d_loss and gp agree at 1e-6, but g_loss = 0.0107 (a saturated discriminator, taken after
+# D's Adam step) spans 7.6e-4 relative over six oracle runs with 1e-7 input noise, and the 8-thread oracle already sits 6.3e-4
+# from the single-threaded reference fixture (tools/knife_edge.py): the knife edge of the batch-2 fixture survives at batch 8
+# for this loss alone, so only g_loss gets the wider bound.
+KNIFE_EDGE = {'c128a3_iqn_b4': 3e-4, 'c128a3_cnn_b256': {'g_loss': 2e-4}, 'c128big_cnn_b8': {'g_loss': 2e-3}}
+
+
+def _loss_tol(case, name, default=1e-4):
+    edge = KNIFE_EDGE.get(case, default)
+    return edge.get(name, default) if isinstance(edge, dict) else edge
 
 
 def _close(a, b, rel, abs_=1e-6):
@@ -68,14 +77,13 @@ def test_hip_trainer_matches_reference_fixture(case):
     for k, ref in enumerate(fx['steps']):
         logs = tr.train_batch(synthetic_images(fx['batch'], fx['size'], fx['img_seed'] + k))
         loss_tol, grad_tol = (1e-4, 2e-3) if k == 0 else (1e-1, 1.0)
-        if k == 0 and case in KNIFE_EDGE:
-            loss_tol = KNIFE_EDGE[case]
         # the G phase runs after D's first Adam step, which moves every weight by ~lr*sign(grad): weights whose
         # true gradient is ~0 get a rounding-determined sign, so G-side gradients are only bounded loosely here
         # (they are pinned tightly, from identical D state, in test_g_phase_gradients_match_oracle)
         g_grad_tol = 2e-2 if k == 0 else 1.0
         for name in ('g_loss', 'd_loss', 'gp'):
-            assert _close(logs[name], ref[name], loss_tol), (case, k, name, logs[name], ref[name])
+            tol = _loss_tol(case, name) if k == 0 else loss_tol
+            assert _close(logs[name], ref[name], tol), (case, k, name, logs[name], ref[name])
         assert _close(_total_l2(tr.g), ref['g_l2'], 1e-4)
         assert _close(_total_l2(tr.d), ref['d_l2'], 1e-4)
         assert _close(_total_l2(tr.target_g), ref['target_g_l2'], 1e-4)
@@ -170,9 +178,8 @@ def test_step2_from_resynchronised_state(case):
     torch.set_rng_state(rng_state)
     got = tr.train_batch(imgs2)
     assert float(torch.rand(1)) == after
-    tol = KNIFE_EDGE.get(case, 1e-4)
     for name in ('g_loss', 'd_loss', 'gp'):
-        assert _close(got[name], want[name], tol), (case, name, got[name], want[name])
+        assert _close(got[name], want[name], _loss_tol(case, name)), (case, name, got[name], want[name])
         # (the oracle is pinned to the reference's step 2 at 2e-5 single-threaded in the build container; on this host's
         # CPU and thread count its free-running step 2 may already sit ~1e-4 away -- the chaos this test sidesteps)
         if has_step2:
