@@ -553,8 +553,42 @@ def deferred_wgrad():
             flush_wgrad()
 
 
+class _WgradStream:
+    """Weight gradients beside the backward's critical path.  In a backward pass the chain is
+    BatchNorm backward (HBM-bound) -> input-gradient convolution (MFMA) -> BatchNorm backward -> ...; a layer's weight
+    gradient hangs off the side of it (it needs the same gy, nothing downstream needs its result before the optimiser).
+    Inside ``deferred_wgrad()`` those launches go to a second stream that forks from the current one where gy is ready and
+    joins it again when the context exits: the MFMA-bound weight gradients then run under the bandwidth-bound BatchNorm
+    passes of the layers below.  Only gradients that accumulate straight into ``.grad`` take this path (nothing on the main
+    stream reads them before the join); their operands are kept alive until the join.  ``TG_WGRAD_STREAM=0`` disables it."""
+    import os as _os
+    enabled = _os.environ.get('TG_WGRAD_STREAM', '1') != '0'
+    stream = None
+    used = False
+
+
+@contextlib.contextmanager
+def _beside_backward(*operands):
+    st = _WgradStream
+    if not (st.enabled and _DeferredWgrad.active and operands[0].is_cuda):
+        yield
+        return
+    if st.stream is None:
+        st.stream = torch.cuda.Stream()
+    st.stream.wait_stream(torch.cuda.current_stream())
+    _DeferredWgrad.keep.append(operands)
+    st.used = True
+    with torch.cuda.stream(st.stream):
+        yield
+
+
 def flush_wgrad():
     st = _DeferredWgrad
+    if _WgradStream.used:
+        torch.cuda.current_stream().wait_stream(_WgradStream.stream)
+        _WgradStream.used = False
+        if not st.items:
+            st.keep = []
     if st.items:
         items, st.items = st.items, []
         try:
@@ -580,7 +614,8 @@ def _conv_wgrad_into(x, gy, gw, gbias, ks, accumulate):
     nbytes = K().conv2d_wgrad_workspace(B, Cin, Cout, H, W, ks)
     if accumulate and _DeferredWgrad.active:
         ws = x.new_empty(nbytes // 4 + 4)               # its own buffer: must survive until the batch reduce
-        K().conv2d_wgrad_partials(x, gy, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks, int(gbias is not None))
+        with _beside_backward(x, gy, ws):
+            K().conv2d_wgrad_partials(x, gy, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks, int(gbias is not None))
         _DeferredWgrad.items.append([ws.data_ptr(), gw.data_ptr(), gbias.data_ptr() if gbias is not None else 0,
                                      B, Cin, Cout, H, W, ks, 1])
         _DeferredWgrad.keep.append((ws, gw, gbias))
@@ -713,8 +748,10 @@ class _UpConv3x3(Function):
                 ws = _ws(a, K().upconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
                 if sink_w is None:
                     gw = torch.empty_like(w)
-                K().upconv3x3_wgrad(a, gy, gw if sink_w is None else sink_w, ws, ws.numel() * 4, B, Cin, Cout, H, W,
-                                    0 if sink_w is None else 1)
+                    K().upconv3x3_wgrad(a, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0)
+                else:
+                    with _beside_backward(a, gy, ws):
+                        K().upconv3x3_wgrad(a, gy, sink_w, ws, ws.numel() * 4, B, Cin, Cout, H, W, 1)
             elif sink_w is not None:
                 _conv_wgrad_into(upsample_nearest2x(a), gy, sink_w, None, 3, accumulate=1)
             else:
@@ -831,8 +868,10 @@ class _PoolConv(Function):
                 ws = _ws(x, K().poolconv3x3_wgrad_workspace(B, Cin, Cout, H2 // 2, W2 // 2))
                 if sink_w is None:
                     gw = torch.empty_like(w)
-                K().poolconv3x3_wgrad(x, gy, gw if sink_w is None else sink_w, ws, ws.numel() * 4, B, Cin, Cout, H2 // 2, W2 // 2,
-                                      0 if sink_w is None else 1)
+                    K().poolconv3x3_wgrad(x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H2 // 2, W2 // 2, 0)
+                else:
+                    with _beside_backward(x, gy, ws):
+                        K().poolconv3x3_wgrad(x, gy, sink_w, ws, ws.numel() * 4, B, Cin, Cout, H2 // 2, W2 // 2, 1)
         if need_b:                                                   # bias gradient at the LOW resolution
             sink_b = _grad_sink(bias)
             if sink_b is not None:
@@ -875,8 +914,10 @@ class _PoolConvT(Function):
                 ws = _ws(v, K().poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
                 if sink is None:
                     a_w = torch.empty_like(w)
-                K().poolconv3x3_wgrad(v, gy, a_w if sink is None else sink, ws, ws.numel() * 4, B, Cin, Cout, H, W,
-                                      0 if sink is None else 1)
+                    K().poolconv3x3_wgrad(v, gy, a_w, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0)
+                else:
+                    with _beside_backward(v, gy, ws):
+                        K().poolconv3x3_wgrad(v, gy, sink, ws, ws.numel() * 4, B, Cin, Cout, H, W, 1)
         return a_gy, a_w
 
 
