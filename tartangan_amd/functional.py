@@ -560,9 +560,12 @@ class _WgradStream:
     Inside ``deferred_wgrad()`` those launches go to a second stream that forks from the current one where gy is ready and
     joins it again when the context exits: the MFMA-bound weight gradients then run under the bandwidth-bound BatchNorm
     passes of the layers below.  Only gradients that accumulate straight into ``.grad`` take this path (nothing on the main
-    stream reads them before the join); their operands are kept alive until the join.  ``TG_WGRAD_STREAM=0`` disables it."""
+    stream reads them before the join); their operands are kept alive until the join.
+    MEASURED (round 3, 128:3 batch 64, graph replay, same box back to back): 10.49 / 10.52 ms per step with it, 9.90 / 9.86
+    without -- the co-running kernels take LDS and issue slots from the convolution kernels on the critical path, which lose
+    more than the overlap gains (round 1 found the same with its register-staged kernels).  OFF unless TG_WGRAD_STREAM=1."""
     import os as _os
-    enabled = _os.environ.get('TG_WGRAD_STREAM', '1') != '0'
+    enabled = _os.environ.get('TG_WGRAD_STREAM', '0') == '1'
     stream = None
     used = False
 
