@@ -966,6 +966,99 @@ static int launch_conv1x1(const float* x, const float* w, const float* bias, con
   return launch_conv1x1_direct<8>(x, w, bias, residual, y, s, dgrad, st);
 }
 
+// =========================================================================== 1x1, streaming MFMA kernel (no LDS)
+// A 1x1 convolution moves 4 (Cin + Cout) bytes per pixel for 2 Cin Cout FLOP: every 1x1 layer of the step is
+// bandwidth- or latency-bound, and the tiled kernel above (patch staging through LDS, barriers, a tile decode per
+// workgroup) gave them 10-16 us each however small the tensor.  Here nothing is staged: a wave owns 64 consecutive
+// pixels (16 lanes x one float4; the flattened (image, pixel / 4) space, so small planes waste nothing) and ALL output
+// channels in 16-channel blocks.  Per k-step of 4 input channels a lane loads ONE float4 of x (lane group h = channel
+// k0 + h, lanes j = 16 neighbouring pixel quads: 1 KiB per wave-load, rows of 256 contiguous bytes) and feeds its four
+// components to four 16x16x4 MFMAs as the B operand -- MFMA r covers the pixels {4 j + r}; the A operand is the filter
+// element (co = 16 m + j, ci = k0 + h), straight from L1.  With lane (j, h) holding D[row 4h + i][col j], the four
+// results of a lane for output channel 16 m + 4 h + i are the pixels 4 j .. 4 j + 3: ONE 16-byte store (and residual
+// load).  No LDS, no barrier, no divergence; the input-gradient form is the same kernel with the filter read transposed.
+template <int NCO>
+__global__ void __launch_bounds__(256)
+conv1x1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                    const float* __restrict__ residual, float* __restrict__ y, int Cin, int Cout, int HW, int64_t quads,
+                    int w_so, int w_si) {
+  const int lane = threadIdx.x & 63, j = lane & 15, h = lane >> 4;
+  const int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + j;      // this lane's pixel quad
+  const bool live = q < quads;
+  const int qpp = HW >> 2;                                                          // quads per plane
+  const int64_t b = live ? q / qpp : 0;
+  const int p = live ? (int)(q - b * qpp) * 4 : 0;
+  const float* xb = x + (b * Cin) * HW + p;
+  f32x4 acc[NCO][4];
+#pragma unroll
+  for (int m = 0; m < NCO; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[m][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // filter rows of this lane: co = 16 m + j (clamped: rows past Cout multiply into accumulators that are never stored)
+  int wrow[NCO];
+#pragma unroll
+  for (int m = 0; m < NCO; ++m) wrow[m] = min(16 * m + j, Cout - 1) * w_so;
+  constexpr int U = 4;                                                              // k-steps whose loads are in flight together
+  for (int k0 = 0; k0 < Cin; k0 += 4 * U) {
+    float4 xv[U];
+    float a[U][NCO];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ci = k0 + 4 * u + h;
+      const bool ok = live && ci < Cin;
+      xv[u] = ok ? *reinterpret_cast<const float4*>(xb + (int64_t)ci * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int cc = min(ci, Cin - 1) * w_si;
+#pragma unroll
+      for (int m = 0; m < NCO; ++m) a[u][m] = (ci < Cin) ? w[wrow[m] + cc] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float bx[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+      for (int m = 0; m < NCO; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][m], bx[r], acc[m][r], 0, 0, 0);
+    }
+  }
+  if (!live) return;
+  float* yb = y + (b * Cout) * HW + p;
+  const float* rb = residual ? residual + (b * Cout) * HW + p : nullptr;
+#pragma unroll
+  for (int m = 0; m < NCO; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = 16 * m + 4 * h + i;
+      if (co >= Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+      float4 o = make_float4(acc[m][0][i] + bv, acc[m][1][i] + bv, acc[m][2][i] + bv, acc[m][3][i] + bv);
+      if (rb) {
+        const float4 t = *reinterpret_cast<const float4*>(rb + (int64_t)co * HW);
+        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+      }
+      *reinterpret_cast<float4*>(yb + (int64_t)co * HW) = o;
+    }
+}
+
+// planes of whole pixel quads, 16-byte aligned tensors, at most 128 output channels (8 accumulator blocks)
+static inline bool conv1x1_mfma_ok(const float* x, const float* residual, const float* y, const Shape& s) {
+  return (s.H * s.W) % 4 == 0 && s.Cout <= 128 && tg_aligned16(x) && tg_aligned16(y) && (!residual || tg_aligned16(residual));
+}
+static int launch_conv1x1_mfma(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, bool dgrad,
+                               hipStream_t st) {
+  const int HW = s.H * s.W;
+  const int64_t quads = (int64_t)s.B * (HW / 4);
+  const int w_so = dgrad ? 1 : s.Cin, w_si = dgrad ? s.Cout : 1;      // (as launch_conv1x1_direct)
+  const unsigned grid = (unsigned)((quads + 63) / 64);                 // 4 waves x 16 quads per workgroup
+  const int nco = (s.Cout + 15) / 16;
+#define TG_1X1(N) conv1x1_mfma_kernel<N><<<grid, 256, 0, st>>>(x, w, bias, residual, y, s.Cin, s.Cout, HW, quads, w_so, w_si)
+  if (nco <= 1) TG_1X1(1);
+  else if (nco == 2) TG_1X1(2);
+  else if (nco <= 4) TG_1X1(4);
+  else TG_1X1(8);
+#undef TG_1X1
+  return tg_launch_status();
+}
+
 // =========================================================================== wgrad
 template <int KS> struct WgCfg {
   static constexpr int CKW = (KS == 3) ? 16 : 32;      // input channels per workgroup
@@ -2552,6 +2645,11 @@ static bool try_launch_dma(const float* x, const float* w, const float* bias, co
   return took;
 }
 
+static int conv1x1_mode() {
+  static const int v = [] { const char* e = getenv("TG_CONV_1X1"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
 template <int KS, bool DGRAD>
 int launch_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
   if constexpr (KS == 3) {
@@ -2561,7 +2659,17 @@ int launch_fwd(const float* x, const float* w, const float* bias, const float* r
   // small layers: if 256-pixel tiles cannot even give every other CU a workgroup, use 64-pixel tiles whose waves
   // split K (4x the workgroups, each wave 1/4 of the k-groups).  Measured at batch 64: 128->128 @ 16^2 (128
   // such workgroups) runs 65 us unsplit vs 74 us split; @ 8^2 (32) 55 us vs 24 us.
-  if (KS == 1 && conv1x1_direct_ok(s)) return launch_conv1x1(x, w, bias, residual, y, s, DGRAD, st);
+  if constexpr (KS == 1) {
+    // Measured at batch 64 (tools/bench_conv.py, us, tiled -> streaming): 3->16 @128^2 26.3 -> 15.0; 16->32 @128^2 (dgrad of
+    // 32->16) 43.4 -> 31.7; 16->32 @64^2 15.6 -> 13.3; but 64->32 @64^2 22.3 -> 26.5 and 128->64 @32^2 21.1 -> 28.2: with
+    // many input channels a wave's serial chain of k-steps is longer than the tiled kernel's four waves sharing a tile.
+    // So: at most 32 input channels, and the few-output-channel VALU kernel keeps its shapes.  (The step as a whole does
+    // not move -- these layers sit at the bandwidth their tensors allow; TG_CONV_1X1 = 0 / 2: never / wherever possible.)
+    const int mode = conv1x1_mode();
+    if (mode != 0 && conv1x1_mfma_ok(x, residual, y, s) && (mode == 2 || (!conv1x1_direct_ok(s) && s.Cin <= 32)))
+      return launch_conv1x1_mfma(x, w, bias, residual, y, s, DGRAD, st);
+    if (conv1x1_direct_ok(s)) return launch_conv1x1(x, w, bias, residual, y, s, DGRAD, st);
+  }
   const GeoId g = pick_geo(s.H, s.W);
   const int64_t wgs256 = (int64_t)geo_tiles(g, s.B, s.H, s.W) * ((s.Cout + 63) / 64);
   const bool ksplit = (g != GEO_X) && wgs256 < 128 && s.Cin >= 16;
