@@ -159,7 +159,8 @@ class KernelTimer:
                 flops = 2.0 * B * Cin * Cout * H * W * 16
                 hi = Cin if name.startswith('poolconv') else Cout      # channels of the high-resolution (2H x 2W) tensor
                 nbytes = 4.0 * (B * hi * 4 * H * W + B * (Cin + Cout - hi) * H * W + Cin * Cout * 16)
-            if name in ('conv2d_fwd', 'conv2d_dgrad') and len(args) >= CONV_DIMS[name].stop and args[CONV_DIMS[name]][5] == 1:
+            if name in ('conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad_partials', 'conv2d_wgrad') and len(args) >= CONV_DIMS[name].stop \
+                    and args[CONV_DIMS[name]][5] == 1:
                 name = name + '_1x1'         # bandwidth-bound (AI = Cin Cout / (2 (Cin + Cout)) FLOP/B << the MFMA ridge)
             d = agg.setdefault(name, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
             d['ms'] += ms
