@@ -1396,6 +1396,118 @@ conv_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
   }
 }
 
+// ---- 1x1 weight gradient, streaming (no operand staging): gw[co][ci] = sum over (image, pixel) of gy[co][p] x[ci][p] is a
+// contraction over pixels with both operands read exactly once -- bandwidth-bound, and the tiled kernel above gave each of
+// the step's two dozen 1x1 layers ~15 us.  Here a wave walks its share of 16-pixel groups; per group a lane loads ONE float4
+// per operand row (lane j = row of the 16-channel block, lane group h = pixels 4h .. 4h+3 of the group: 16 rows x 64
+// contiguous bytes per wave-load, consecutive groups continue the same rows) and the four components feed four 16x16x4
+// MFMAs (k-step r contracts the pixels {4h + r}).  Per-workgroup partials in the layout of conv_wgrad_kernel (same plan,
+// same reduce kernels, fixed summation order => deterministic); the bias gradient is the sum of the A operands.
+template <int MT, int NT>
+__global__ void __launch_bounds__(256)
+conv1x1_wgrad_stream_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part,
+                            float* __restrict__ bias_part /*nullable: [S][Cout]*/, int Cin, int Cout, int HW, int64_t groups, int S) {
+  __shared__ float red[4 * MT * NT * 4 * 64 + 4 * 16 * MT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, h = lane >> 4;
+  const int co0 = blockIdx.y * 16 * MT, ci0 = blockIdx.z * 16 * NT, split = blockIdx.x;
+  const int64_t g_begin = groups * split / S, g_end = groups * (split + 1) / S;
+  const int64_t n = g_end - g_begin;
+  const int64_t w_begin = g_begin + n * wave / 4, w_end = g_begin + n * (wave + 1) / 4;
+  const int gpp = HW >> 4;                                   // 16-pixel groups per plane
+  int64_t arow[MT], brow[NT];                                // row offsets (clamped: rows past the tensor are never written)
+#pragma unroll
+  for (int m = 0; m < MT; ++m) arow[m] = (int64_t)min(co0 + 16 * m + j, Cout - 1) * HW + 4 * h;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) brow[t] = (int64_t)min(ci0 + 16 * t + j, Cin - 1) * HW + 4 * h;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) bsum[m] = 0.f;
+  constexpr int U = 4;                                       // groups whose loads are in flight together
+  for (int64_t g0 = w_begin; g0 < w_end; g0 += U) {
+    float4 ga[U][MT], xb[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t g = g0 + u;
+      const bool ok = g < w_end;
+      const int64_t b = ok ? g / gpp : 0;
+      const int64_t p = ok ? (g - b * gpp) * 16 : 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        ga[u][m] = ok ? *reinterpret_cast<const float4*>(gy + b * Cout * HW + arow[m] + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        xb[u][t] = ok ? *reinterpret_cast<const float4*>(x + b * Cin * HW + brow[t] + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) bsum[m] += (ga[u][m].x + ga[u][m].y) + (ga[u][m].z + ga[u][m].w);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float av[4] = {ga[u][m].x, ga[u][m].y, ga[u][m].z, ga[u][m].w};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float bv[4] = {xb[u][t].x, xb[u][t].y, xb[u][t].z, xb[u][t].w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r], acc[m][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // cross-wave sums through LDS, fixed order
+  constexpr int PER_WAVE = MT * NT * 4 * 64;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[wave * PER_WAVE + ((m * NT + t) * 4 + i) * 64 + lane] = acc[m][t][i];
+  float* bred = red + 4 * PER_WAVE;                          // [wave][16 MT]
+  const bool do_bias = bias_part != nullptr && blockIdx.z == 0;
+  if (do_bias) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float v = bsum[m];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (h == 0) bred[wave * 16 * MT + 16 * m + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < PER_WAVE; e += 256) {
+    const float v = (red[e] + red[PER_WAVE + e]) + (red[2 * PER_WAVE + e] + red[3 * PER_WAVE + e]);
+    const int l = e & 63, q = e >> 6;
+    const int i = q & 3, t = (q >> 2) % NT, m = (q >> 2) / NT;
+    const int co = co0 + 16 * m + 4 * (l >> 4) + i, ci = ci0 + 16 * t + (l & 15);      // lane (j, h): D[row 4h + i][col j]
+    if (co < Cout && ci < Cin) part[((int64_t)split * Cout + co) * Cin + ci] = v;
+  }
+  if (do_bias && threadIdx.x < 16 * MT && co0 + (int)threadIdx.x < Cout) {
+    const int c = threadIdx.x;
+    bias_part[(int64_t)split * Cout + co0 + c] = (bred[c] + bred[16 * MT + c]) + (bred[2 * 16 * MT + c] + bred[3 * 16 * MT + c]);
+  }
+}
+
+static int conv1x1_mode();
+static inline bool conv1x1_wgrad_stream_ok(const float* x, const float* gy, const Shape& s) {
+  return conv1x1_mode() != 0 && (s.H * s.W) % 16 == 0 && tg_aligned16(x) && tg_aligned16(gy);
+}
+static int launch_conv1x1_wgrad_stream(const float* x, const float* gy, float* part, float* bias_part, Shape s, int S, hipStream_t st) {
+  const int HW = s.H * s.W;
+  const int64_t groups = (int64_t)s.B * (HW / 16);
+  const int mt = s.Cout > 16 ? 2 : 1, nt = s.Cin > 16 ? 2 : 1;
+  dim3 grid(S, (s.Cout + 16 * mt - 1) / (16 * mt), (s.Cin + 16 * nt - 1) / (16 * nt));
+  if (mt == 1 && nt == 1) conv1x1_wgrad_stream_kernel<1, 1><<<grid, 256, 0, st>>>(x, gy, part, bias_part, s.Cin, s.Cout, HW, groups, S);
+  else if (mt == 1) conv1x1_wgrad_stream_kernel<1, 2><<<grid, 256, 0, st>>>(x, gy, part, bias_part, s.Cin, s.Cout, HW, groups, S);
+  else if (nt == 1) conv1x1_wgrad_stream_kernel<2, 1><<<grid, 256, 0, st>>>(x, gy, part, bias_part, s.Cin, s.Cout, HW, groups, S);
+  else conv1x1_wgrad_stream_kernel<2, 2><<<grid, 256, 0, st>>>(x, gy, part, bias_part, s.Cin, s.Cout, HW, groups, S);
+  return tg_launch_status();
+}
+
 // gw[e] (+)= sum_s part[s][e], fixed order.  64 consecutive e per workgroup (coalesced), the S partials
 // are split over the 4 waves and combined through LDS: no serial chain of S dependent loads.
 // Workgroups past ceil(E/64) reduce the bias partials the same way.
@@ -2739,6 +2851,9 @@ int launch_wgrad_geo(const float* x, const float* gy, float* part, float* bias_p
         }
       }
     }
+  }
+  if constexpr (KS == 1) {
+    if (conv1x1_wgrad_stream_ok(x, gy, s)) return launch_conv1x1_wgrad_stream(x, gy, part, bias_part, s, p.S, st);
   }
   if (p.mtw == 2) conv_wgrad_kernel<G, KS, 2><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S, vx, vg);
   else conv_wgrad_kernel<G, KS, 1><<<grid, CT_THREADS, 0, st>>>(x, gy, part, bias_part, s, p.tiles, p.S, vx, vg);
