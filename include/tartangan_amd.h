@@ -100,6 +100,20 @@ size_t tg_conv2d_wgrad_workspace(int B, int Cin, int Cout, int H, int W, int ks)
 int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* gbias /*nullable*/,
                     float* workspace, size_t workspace_bytes,
                     int B, int Cin, int Cout, int H, int W, int ks, int accumulate, void* stream);
+/* SelfAttention2d's theta / phi / g projections (attention.py:15-17, 22-26: three bias-free 1x1 convolutions of the SAME input)
+ * as ONE pass each way: x is read once for the three outputs, the three output gradients give the input gradient in one pass
+ * (no three-way add) and the three filter gradients in one pass.  w / gw: the three filters back to back,
+ * [c0 + c1 + c2][Cin] (they are adjacent in the parameter bucket); y_k / gy_k: (B, c_k, H, W) each.  Bandwidth-bound
+ * streaming kernels (no LDS); need H*W % 16 == 0, at most 128 channels either side, 16-byte aligned tensors. */
+int tg_conv1x1_multi_supported(int c0, int c1, int c2, int B, int Cin, int H, int W);
+int tg_conv1x1_multi_fwd(const float* x, const float* w, float* y0, float* y1, float* y2, int c0, int c1, int c2,
+                         int B, int Cin, int H, int W, void* stream);
+int tg_conv1x1_multi_dgrad(const float* gy0, const float* gy1, const float* gy2, const float* w, float* gx,
+                           int c0, int c1, int c2, int B, int Cin, int H, int W, void* stream);
+size_t tg_conv1x1_multi_wgrad_workspace(int c0, int c1, int c2, int B, int Cin, int H, int W);
+int tg_conv1x1_multi_wgrad(const float* x, const float* gy0, const float* gy1, const float* gy2, float* gw,
+                           float* workspace, size_t workspace_bytes, int c0, int c1, int c2, int B, int Cin, int H, int W,
+                           int accumulate /* gw += */, void* stream);
 /* The same in two steps, so that ONE launch can finish the reduction for many layers (a whole backward pass):
  *   tg_conv2d_wgrad_partials     stage 1 only: per-workgroup partial sums into `workspace` (which must then stay
  *                                untouched until the batch reduce has run);

@@ -977,10 +977,32 @@ static int launch_conv1x1(const float* x, const float* w, const float* bias, con
 // element (co = 16 m + j, ci = k0 + h), straight from L1.  With lane (j, h) holding D[row 4h + i][col j], the four
 // results of a lane for output channel 16 m + 4 h + i are the pixels 4 j .. 4 j + 3: ONE 16-byte store (and residual
 // load).  No LDS, no barrier, no divergence; the input-gradient form is the same kernel with the filter read transposed.
+// Channel segments: the channels of the input and / or the output may be spread over up to three tensors (SelfAttention2d's
+// theta / phi / g projections read ONE x: their outputs are three tensors, the inputs of their joint input gradient likewise).
+// Channel c of a segmented operand lives in tensor k with start[k] <= c < start[k + 1], as its channel c - start[k].
+struct ChanSegs {
+  float* p[3];
+  int start[4];                     // start[0] = 0, start[n] = all channels; unused entries = start[n]
+  __device__ __forceinline__ int find(int c) const { return c >= start[2] ? 2 : (c >= start[1] ? 1 : 0); }
+  __device__ __forceinline__ int width(int k) const { return start[k + 1] - start[k]; }
+};
+static inline ChanSegs one_seg(const float* p, int channels) {
+  ChanSegs g;
+  g.p[0] = g.p[1] = g.p[2] = const_cast<float*>(p);
+  g.start[0] = 0; g.start[1] = g.start[2] = g.start[3] = channels;
+  return g;
+}
+static inline ChanSegs three_segs(const float* p0, const float* p1, const float* p2, int c0, int c1, int c2) {
+  ChanSegs g;
+  g.p[0] = const_cast<float*>(p0); g.p[1] = const_cast<float*>(p1); g.p[2] = const_cast<float*>(p2);
+  g.start[0] = 0; g.start[1] = c0; g.start[2] = c0 + c1; g.start[3] = c0 + c1 + c2;
+  return g;
+}
+
 template <int NCO>
 __global__ void __launch_bounds__(256)
-conv1x1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                    const float* __restrict__ residual, float* __restrict__ y, int Cin, int Cout, int HW, int64_t quads,
+conv1x1_mfma_kernel(ChanSegs xs, const float* __restrict__ w, const float* __restrict__ bias,
+                    const float* __restrict__ residual, ChanSegs ys, int Cin, int Cout, int HW, int64_t quads,
                     int w_so, int w_si) {
   const int lane = threadIdx.x & 63, j = lane & 15, h = lane >> 4;
   const int64_t q = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + j;      // this lane's pixel quad
@@ -988,7 +1010,6 @@ conv1x1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, co
   const int qpp = HW >> 2;                                                          // quads per plane
   const int64_t b = live ? q / qpp : 0;
   const int p = live ? (int)(q - b * qpp) * 4 : 0;
-  const float* xb = x + (b * Cin) * HW + p;
   f32x4 acc[NCO][4];
 #pragma unroll
   for (int m = 0; m < NCO; ++m)
@@ -1006,10 +1027,12 @@ conv1x1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, co
     for (int u = 0; u < U; ++u) {
       const int ci = k0 + 4 * u + h;
       const bool ok = live && ci < Cin;
-      xv[u] = ok ? *reinterpret_cast<const float4*>(xb + (int64_t)ci * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const int cc = min(ci, Cin - 1) * w_si;
+      const int cc = min(ci, Cin - 1);
+      const int k = xs.find(cc);
+      const float* src = xs.p[k] + ((b * xs.width(k) + (cc - xs.start[k])) * HW + p);
+      xv[u] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int m = 0; m < NCO; ++m) a[u][m] = (ci < Cin) ? w[wrow[m] + cc] : 0.f;
+      for (int m = 0; m < NCO; ++m) a[u][m] = (ci < Cin) ? w[wrow[m] + cc * w_si] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1021,7 +1044,6 @@ conv1x1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, co
     }
   }
   if (!live) return;
-  float* yb = y + (b * Cout) * HW + p;
   const float* rb = residual ? residual + (b * Cout) * HW + p : nullptr;
 #pragma unroll
   for (int m = 0; m < NCO; ++m)
@@ -1035,7 +1057,8 @@ conv1x1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, co
         const float4 t = *reinterpret_cast<const float4*>(rb + (int64_t)co * HW);
         o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
       }
-      *reinterpret_cast<float4*>(yb + (int64_t)co * HW) = o;
+      const int k = ys.find(co);
+      *reinterpret_cast<float4*>(ys.p[k] + ((b * ys.width(k) + (co - ys.start[k])) * HW + p)) = o;
     }
 }
 
@@ -1043,20 +1066,24 @@ conv1x1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, co
 static inline bool conv1x1_mfma_ok(const float* x, const float* residual, const float* y, const Shape& s) {
   return (s.H * s.W) % 4 == 0 && s.Cout <= 128 && tg_aligned16(x) && tg_aligned16(y) && (!residual || tg_aligned16(residual));
 }
-static int launch_conv1x1_mfma(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, bool dgrad,
+static int launch_conv1x1_segs(ChanSegs xs, const float* w, const float* bias, const float* residual, ChanSegs ys, Shape s, bool dgrad,
                                hipStream_t st) {
   const int HW = s.H * s.W;
   const int64_t quads = (int64_t)s.B * (HW / 4);
   const int w_so = dgrad ? 1 : s.Cin, w_si = dgrad ? s.Cout : 1;      // (as launch_conv1x1_direct)
   const unsigned grid = (unsigned)((quads + 63) / 64);                 // 4 waves x 16 quads per workgroup
   const int nco = (s.Cout + 15) / 16;
-#define TG_1X1(N) conv1x1_mfma_kernel<N><<<grid, 256, 0, st>>>(x, w, bias, residual, y, s.Cin, s.Cout, HW, quads, w_so, w_si)
+#define TG_1X1(N) conv1x1_mfma_kernel<N><<<grid, 256, 0, st>>>(xs, w, bias, residual, ys, s.Cin, s.Cout, HW, quads, w_so, w_si)
   if (nco <= 1) TG_1X1(1);
   else if (nco == 2) TG_1X1(2);
   else if (nco <= 4) TG_1X1(4);
   else TG_1X1(8);
 #undef TG_1X1
   return tg_launch_status();
+}
+static int launch_conv1x1_mfma(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, bool dgrad,
+                               hipStream_t st) {
+  return launch_conv1x1_segs(one_seg(x, s.Cin), w, bias, residual, one_seg(y, s.Cout), s, dgrad, st);
 }
 
 // =========================================================================== wgrad
@@ -1405,7 +1432,7 @@ conv_wgrad_dma_kernel(const float* __restrict__ x, const float* __restrict__ gy,
 // same reduce kernels, fixed summation order => deterministic); the bias gradient is the sum of the A operands.
 template <int MT, int NT>
 __global__ void __launch_bounds__(256)
-conv1x1_wgrad_stream_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part,
+conv1x1_wgrad_stream_kernel(const float* __restrict__ x, ChanSegs gys, float* __restrict__ part,
                             float* __restrict__ bias_part /*nullable: [S][Cout]*/, int Cin, int Cout, int HW, int64_t groups, int S) {
   __shared__ float red[4 * MT * NT * 4 * 64 + 4 * 16 * MT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, h = lane >> 4;
@@ -1414,9 +1441,15 @@ conv1x1_wgrad_stream_kernel(const float* __restrict__ x, const float* __restrict
   const int64_t n = g_end - g_begin;
   const int64_t w_begin = g_begin + n * wave / 4, w_end = g_begin + n * (wave + 1) / 4;
   const int gpp = HW >> 4;                                   // 16-pixel groups per plane
-  int64_t arow[MT], brow[NT];                                // row offsets (clamped: rows past the tensor are never written)
+  int64_t arow[MT], brow[NT], aimg[MT];                      // row offsets (clamped: rows past the tensor are never written)
+  const float* abase[MT];                                    // gy rows may come from up to three tensors (ChanSegs)
 #pragma unroll
-  for (int m = 0; m < MT; ++m) arow[m] = (int64_t)min(co0 + 16 * m + j, Cout - 1) * HW + 4 * h;
+  for (int m = 0; m < MT; ++m) {
+    const int co = min(co0 + 16 * m + j, Cout - 1), k = gys.find(co);
+    abase[m] = gys.p[k];
+    aimg[m] = (int64_t)gys.width(k) * HW;
+    arow[m] = (int64_t)(co - gys.start[k]) * HW + 4 * h;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) brow[t] = (int64_t)min(ci0 + 16 * t + j, Cin - 1) * HW + 4 * h;
   f32x4 acc[MT][NT];
@@ -1438,7 +1471,7 @@ conv1x1_wgrad_stream_kernel(const float* __restrict__ x, const float* __restrict
       const int64_t p = ok ? (g - b * gpp) * 16 : 0;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
-        ga[u][m] = ok ? *reinterpret_cast<const float4*>(gy + b * Cout * HW + arow[m] + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ga[u][m] = ok ? *reinterpret_cast<const float4*>(abase[m] + b * aimg[m] + arow[m] + p) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         xb[u][t] = ok ? *reinterpret_cast<const float4*>(x + b * Cin * HW + brow[t] + p) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1496,7 +1529,7 @@ static int conv1x1_mode();
 static inline bool conv1x1_wgrad_stream_ok(const float* x, const float* gy, const Shape& s) {
   return conv1x1_mode() != 0 && (s.H * s.W) % 16 == 0 && tg_aligned16(x) && tg_aligned16(gy);
 }
-static int launch_conv1x1_wgrad_stream(const float* x, const float* gy, float* part, float* bias_part, Shape s, int S, hipStream_t st) {
+static int launch_conv1x1_wgrad_segs(const float* x, ChanSegs gy, float* part, float* bias_part, Shape s, int S, hipStream_t st) {
   const int HW = s.H * s.W;
   const int64_t groups = (int64_t)s.B * (HW / 16);
   const int mt = s.Cout > 16 ? 2 : 1, nt = s.Cin > 16 ? 2 : 1;
@@ -1506,6 +1539,9 @@ static int launch_conv1x1_wgrad_stream(const float* x, const float* gy, float* p
   else if (nt == 1) conv1x1_wgrad_stream_kernel<2, 1><<<grid, 256, 0, st>>>(x, gy, part, bias_part, s.Cin, s.Cout, HW, groups, S);
   else conv1x1_wgrad_stream_kernel<2, 2><<<grid, 256, 0, st>>>(x, gy, part, bias_part, s.Cin, s.Cout, HW, groups, S);
   return tg_launch_status();
+}
+static int launch_conv1x1_wgrad_stream(const float* x, const float* gy, float* part, float* bias_part, Shape s, int S, hipStream_t st) {
+  return launch_conv1x1_wgrad_segs(x, one_seg(gy, s.Cout), part, bias_part, s, S, st);
 }
 
 // gw[e] (+)= sum_s part[s][e], fixed order.  64 consecutive e per workgroup (coalesced), the S partials
@@ -3096,6 +3132,52 @@ int tg_conv2d_wgrad_partials(const float* x, const float* gy, float* workspace, 
   TG_CHECK_PTR(x); TG_CHECK_PTR(gy); TG_CHECK_PTR(workspace);
   WgPlan p;
   return wgrad_partials(x, gy, workspace, workspace_bytes, B, Cin, Cout, H, W, ks, want_bias, tg_stream(stream), &p);
+}
+
+// ---- SelfAttention2d's three projections of one input (theta, phi, g) as one pass each way
+static inline bool qkv_ok(int c0, int c1, int c2, int B, int Cin, int H, int W) {
+  const int C = c0 + c1 + c2;
+  return c0 > 0 && c1 > 0 && c2 > 0 && C <= 128 && Cin <= 128 && (H * W) % 16 == 0 && check_shape(B, Cin, C, H, W, 1) == TG_OK;
+}
+int tg_conv1x1_multi_supported(int c0, int c1, int c2, int B, int Cin, int H, int W) { return qkv_ok(c0, c1, c2, B, Cin, H, W) ? 1 : 0; }
+
+int tg_conv1x1_multi_fwd(const float* x, const float* w, float* y0, float* y1, float* y2, int c0, int c1, int c2, int B, int Cin,
+                         int H, int W, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(w); TG_CHECK_PTR(y0); TG_CHECK_PTR(y1); TG_CHECK_PTR(y2);
+  if (!qkv_ok(c0, c1, c2, B, Cin, H, W)) return TG_EUNSUPPORTED;
+  if (!tg_aligned16(x) || !tg_aligned16(y0) || !tg_aligned16(y1) || !tg_aligned16(y2)) return TG_EUNSUPPORTED;
+  Shape s{B, Cin, c0 + c1 + c2, H, W};
+  return launch_conv1x1_segs(one_seg(x, Cin), w, nullptr, nullptr, three_segs(y0, y1, y2, c0, c1, c2), s, false, tg_stream(stream));
+}
+
+int tg_conv1x1_multi_dgrad(const float* gy0, const float* gy1, const float* gy2, const float* w, float* gx, int c0, int c1, int c2,
+                           int B, int Cin, int H, int W, void* stream) {
+  TG_CHECK_PTR(gy0); TG_CHECK_PTR(gy1); TG_CHECK_PTR(gy2); TG_CHECK_PTR(w); TG_CHECK_PTR(gx);
+  if (!qkv_ok(c0, c1, c2, B, Cin, H, W)) return TG_EUNSUPPORTED;
+  if (!tg_aligned16(gx) || !tg_aligned16(gy0) || !tg_aligned16(gy1) || !tg_aligned16(gy2)) return TG_EUNSUPPORTED;
+  // as an operation: c0 + c1 + c2 input channels (the three gradients), Cin output channels, the forward filter read transposed
+  Shape s{B, c0 + c1 + c2, Cin, H, W};
+  return launch_conv1x1_segs(three_segs(gy0, gy1, gy2, c0, c1, c2), w, nullptr, nullptr, one_seg(gx, Cin), s, true, tg_stream(stream));
+}
+
+size_t tg_conv1x1_multi_wgrad_workspace(int c0, int c1, int c2, int B, int Cin, int H, int W) {
+  return tg_conv2d_wgrad_workspace(B, Cin, c0 + c1 + c2, H, W, 1);
+}
+
+int tg_conv1x1_multi_wgrad(const float* x, const float* gy0, const float* gy1, const float* gy2, float* gw, float* workspace,
+                           size_t workspace_bytes, int c0, int c1, int c2, int B, int Cin, int H, int W, int accumulate, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(gy0); TG_CHECK_PTR(gy1); TG_CHECK_PTR(gy2); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
+  if (!qkv_ok(c0, c1, c2, B, Cin, H, W)) return TG_EUNSUPPORTED;
+  if (!tg_aligned16(x) || !tg_aligned16(gy0) || !tg_aligned16(gy1) || !tg_aligned16(gy2)) return TG_EUNSUPPORTED;
+  const int C = c0 + c1 + c2;
+  if (workspace_bytes < tg_conv2d_wgrad_workspace(B, Cin, C, H, W, 1)) return TG_EWORKSPACE;
+  const WgPlan p = wgrad_plan(B, Cin, C, H, W, 1);
+  Shape s{B, Cin, C, H, W};
+  hipStream_t st = tg_stream(stream);
+  if (int rc = launch_conv1x1_wgrad_segs(x, three_segs(gy0, gy1, gy2, c0, c1, c2), workspace, nullptr, s, p.S, st)) return rc;
+  const int64_t E = (int64_t)C * Cin;
+  wgrad_reduce_kernel<<<(int)((E + 63) / 64), 256, 0, st>>>(workspace, gw, E, p.S, nullptr, nullptr, C, accumulate);
+  return tg_launch_status();
 }
 
 int tg_conv2d_wgrad_reduce_batch(const tg_host_i64* items, int n_items, void* stream) {

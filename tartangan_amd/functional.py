@@ -691,6 +691,113 @@ def conv2d(x, weight, bias=None, residual=None, residual_up=False):
 PAIR_SPECS[_ConvFwd] = ('b--b-', 'h--', 'b')
 
 
+# =========================================================================== theta | phi | g of SelfAttention2d
+def _adjacent(ts):
+    """One (rows, cols) view over tensors that lie back to back in one storage (the parameters of a network, and their
+    gradients, do: tartangan_amd.optim keeps each network in one flat bucket, in registration order), else None."""
+    first = ts[0]
+    if first is None:
+        return None
+    cols = first[0].numel()
+    off = first.storage_offset()
+    for t in ts:
+        if (t is None or not t.is_contiguous() or t[0].numel() != cols or t.dtype != first.dtype
+                or t.untyped_storage().data_ptr() != first.untyped_storage().data_ptr() or t.storage_offset() != off):
+            return None
+        off += t.numel()
+    return first.as_strided((sum(t.shape[0] for t in ts), cols), (cols, 1), first.storage_offset())
+
+
+def _stacked(ws):
+    view = _adjacent(ws)
+    return view if view is not None else torch.cat([w.reshape(w.shape[0], -1) for w in ws])
+
+
+def _qkv_wgrad(x, gys, ws, need):
+    """Filter gradients of the three projections from (x, their output gradients): ONE pass over x when the three ``.grad``
+    buffers can be written in place as one matrix, else the generic (differentiable) per-layer path."""
+    if not any(need) or not _param_grads_wanted():
+        return [None, None, None]
+    sinks = [_grad_sink(w) for w in ws]
+    cat = _adjacent(sinks) if all(need) and all(sk is not None for sk in sinks) else None
+    if cat is None:
+        return [_ConvWgrad.apply(x, g, 1) if n else None for g, n in zip(gys, need)]
+    B, Cin, H, W = x.shape
+    cs = [w.shape[0] for w in ws]
+    nbytes = K().conv1x1_multi_wgrad_workspace(*cs, B, Cin, H, W)
+    wsb = _ws(x, nbytes)
+    K().conv1x1_multi_wgrad(x, gys[0], gys[1], gys[2], cat, wsb, wsb.numel() * 4, *cs, B, Cin, H, W, 1)
+    return [None, None, None]
+
+
+class _QKV(Function):
+    """(conv1x1(x, w_theta), conv1x1(x, w_phi), conv1x1(x, w_g)) of SelfAttention2d (attention.py:22-26) in one pass over x
+    (tg_conv1x1_multi_*); backward: one pass for the input gradient (no three-way add), one for the three filter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, wt, wp, wg):
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        cs = (wt.shape[0], wp.shape[0], wg.shape[0])
+        ys = [x.new_empty(B, c, H, W) for c in cs]
+        K().conv1x1_multi_fwd(x, _stacked((wt, wp, wg)), ys[0], ys[1], ys[2], *cs, B, Cin, H, W)
+        ctx.save_for_backward(x, wt, wp, wg)
+        ctx.data_input = is_data(x)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, gt, gp, gg):
+        x, wt, wp, wg = ctx.saved_tensors
+        gys = [g.contiguous() for g in (gt, gp, gg)]
+        gx = None
+        if ctx.needs_input_grad[0] and not _skip_input_grad(ctx):
+            gx = _QKVDgrad.apply(gys[0], gys[1], gys[2], wt, wp, wg)
+        gws = _qkv_wgrad(x, gys, (wt, wp, wg), ctx.needs_input_grad[1:4])
+        return (gx, *gws)
+
+
+class _QKVDgrad(Function):
+    """sum_k conv1x1_dgrad(gy_k, w_k): the input gradient of ``_QKV``; its own backward closes the loop (R1 penalty)."""
+
+    @staticmethod
+    def forward(ctx, gt, gp, gg, wt, wp, wg):
+        gys = [g.contiguous() for g in (gt, gp, gg)]
+        B, _, H, W = gys[0].shape
+        Cin = wt[0].numel()
+        cs = (wt.shape[0], wp.shape[0], wg.shape[0])
+        gx = gys[0].new_empty(B, Cin, H, W)
+        K().conv1x1_multi_dgrad(gys[0], gys[1], gys[2], _stacked((wt, wp, wg)), gx, *cs, B, Cin, H, W)
+        ctx.save_for_backward(gys[0], gys[1], gys[2], wt, wp, wg)
+        return gx
+
+    @staticmethod
+    def backward(ctx, v):
+        gt, gp, gg, wt, wp, wg = ctx.saved_tensors
+        v = v.contiguous()
+        a_g = [None, None, None]
+        if any(ctx.needs_input_grad[:3]):
+            a_g = list(_QKV.apply(v, wt, wp, wg))
+        # (the R1 penalty's contribution to the three filter gradients: the same product with v in the place of x)
+        a_w = _qkv_wgrad(v, (gt, gp, gg), (wt, wp, wg), ctx.needs_input_grad[3:6])
+        return (*a_g, *a_w)
+
+
+def qkv_supported(x, w_theta, w_phi, w_g):
+    B, Cin, H, W = x.shape
+    cs = (w_theta.shape[0], w_phi.shape[0], w_g.shape[0])
+    return all(bool(K().conv1x1_multi_supported(*cs, b, Cin, H, W)) for b in ((B, B // 2) if _is_pair(x) else (B,)))
+
+
+def qkv_projections(x, w_theta, w_phi, w_g):
+    """-> (theta(x), phi(x), g(x)): three bias-free 1x1 convolutions of one input, one pass."""
+    if _is_pair(x):
+        return pair_apply(_QKV, x, w_theta, w_phi, w_g)
+    return _QKV.apply(x, w_theta, w_phi, w_g)
+
+
+PAIR_SPECS[_QKV] = ('b---', 'h---', 'bbb')
+
+
 # =========================================================================== GEMM
 class _UpConv3x3(Function):
     """conv3x3(nearest_up2x(a)) + bias [+ residual] as four 2x2-tap convolutions at the low resolution

@@ -26,15 +26,28 @@ class SelfAttention2d(nn.Module):
         self.o = Conv2d(in_dims // 2, in_dims, 1, bias=False)
         self.gamma = nn.Parameter(torch.tensor(0.), requires_grad=True)
 
+    fuse_projections = True
+
+    def _projections_fuse(self, x):
+        plain = all(type(m) is Conv2d and m.bias is None and m.kernel_size == (1, 1) for m in (self.theta, self.phi, self.g))
+        return (self.fuse_projections and plain and x.dim() == 4
+                and TF.qkv_supported(x, self.theta.weight, self.phi.weight, self.g.weight))
+
     def forward(self, x, y=None):
         b, c, h, w = x.shape
         n = h * w
-        if x.requires_grad and torch.is_grad_enabled():
-            xt, xp, xg, xr = TF.fork(x, 4)       # four consumers: their gradients meet in one kernel, not three autograd adds
+        tracked = x.requires_grad and torch.is_grad_enabled()
+        if self._projections_fuse(x):
+            # theta, phi, g read the same x: one pass for the three maps (and, backwards, for their joint input gradient
+            # and their filter gradients) instead of three -- x has two consumers left
+            xq, xr = TF.fork(x, 2) if tracked else (x, x)
+            theta, phi, g = TF.qkv_projections(xq, self.theta.weight, self.phi.weight, self.g.weight)
         else:
-            xt = xp = xg = xr = x
-        theta = self.theta(xt).view(b, c // 8, n)
-        phi = TF.max_pool2(self.phi(xp)).view(b, c // 8, n // 4)
-        g = TF.max_pool2(self.g(xg)).view(b, c // 2, n // 4)
+            # four consumers: their gradients meet in one kernel, not three autograd adds
+            xt, xp, xg, xr = TF.fork(x, 4) if tracked else (x, x, x, x)
+            theta, phi, g = self.theta(xt), self.phi(xp), self.g(xg)
+        theta = theta.view(b, c // 8, n)
+        phi = TF.max_pool2(phi).view(b, c // 8, n // 4)
+        g = TF.max_pool2(g).view(b, c // 2, n // 4)
         o = TF.attention_core(theta, phi, g).view(b, c // 2, h, w)          # g softmax(theta^T phi)^T
         return TF.scale_add(self.gamma, self.o(o), xr)

@@ -122,6 +122,30 @@ class Emulator:
         gw.copy_(gw + r if accumulate else r)
         return 0
 
+    # theta | phi | g of SelfAttention2d as one pass: the three 1x1 convolutions, their joint input gradient, their filter gradients
+    def conv1x1_multi_supported(self, c0, c1, c2, B, Cin, H, W):
+        return int((H * W) % 16 == 0 and c0 + c1 + c2 <= 128 and Cin <= 128)
+
+    def conv1x1_multi_fwd(self, x, w, y0, y1, y2, c0, c1, c2, B, Cin, H, W):
+        r = F.conv2d(_v(x, B, Cin, H, W), _v(w, c0 + c1 + c2, Cin, 1, 1))
+        for y, part in zip((y0, y1, y2), torch.split(r, [c0, c1, c2], 1)):
+            y.copy_(part)
+        return 0
+
+    def conv1x1_multi_dgrad(self, gy0, gy1, gy2, w, gx, c0, c1, c2, B, Cin, H, W):
+        gy = torch.cat([_v(gy0, B, c0, H, W), _v(gy1, B, c1, H, W), _v(gy2, B, c2, H, W)], 1)
+        gx.copy_(F.conv_transpose2d(gy, _v(w, c0 + c1 + c2, Cin, 1, 1)))
+        return 0
+
+    def conv1x1_multi_wgrad_workspace(self, c0, c1, c2, B, Cin, H, W):
+        return 16
+
+    def conv1x1_multi_wgrad(self, x, gy0, gy1, gy2, gw, ws, ws_bytes, c0, c1, c2, B, Cin, H, W, accumulate):
+        gy = torch.cat([_v(gy0, B, c0, H, W), _v(gy1, B, c1, H, W), _v(gy2, B, c2, H, W)], 1)
+        r = torch.einsum('bchw,bdhw->cd', gy, _v(x, B, Cin, H, W)).reshape(gw.shape)
+        gw.copy_(gw + r if accumulate else r)
+        return 0
+
     def conv2d_dgrad(self, gy, w, gx, B, Cin, Cout, H, W, ks):
         gx.copy_(F.conv_transpose2d(_v(gy, B, Cout, H, W), _v(w, Cout, Cin, ks, ks), padding=ks // 2))
         return 0

@@ -516,3 +516,42 @@ def test_generator_forwards_of_both_phases_share_one_pass(kind, single_thread):
             assert torch.allclose(gp_[k], gs[k], rtol=1e-5, atol=1e-6), k
         else:
             assert float((gp_[k] - gs[k]).abs().max()) <= 2.1 * 1e-4 + 1e-6, k          # Adam's +-lr sign noise (see above)
+
+
+@pytest.mark.parametrize('kind', ['cnn', 'iqn'])
+def test_fused_attention_projections_equal_three_separate_convolutions(kind, single_thread):
+    """theta | phi | g of SelfAttention2d as one pass (forward, joint input gradient, filter gradients, and the R1 second-order
+    terms through them) against the three separate 1x1 convolutions: same losses, same parameter gradients."""
+    from tartangan_amd.models.blocks import SelfAttention2d
+    cls = {'cnn': CNNTrainer, 'iqn': IQNTrainer}[kind]
+    cfg = GAN_CONFIGS['32']._replace(attention=(1,))
+    res = []
+    try:
+        for fused in (True, False):
+            SelfAttention2d.fuse_projections = fused
+            tr = cls(cls.default_args(config=cfg, batch_size=6, device='cpu'))
+            torch.manual_seed(0)
+            tr.build_models()
+            tr.g.load_state_dict(procedural_state(tr.g.state_dict(), 7))
+            tr.d.load_state_dict(procedural_state(tr.d.state_dict(), 9))
+            with torch.no_grad():                                   # gamma = 0 would switch the attention branch off
+                for net in (tr.g, tr.d):
+                    for m in net.modules():
+                        if isinstance(m, SelfAttention2d):
+                            m.gamma.fill_(0.7)
+            tr.g.train(); tr.d.train()
+            torch.manual_seed(5)
+            d_loss, gp = tr._d_phase(synthetic_images(6, 32, 99))
+            d_grads = {n: p.grad.clone() for n, p in tr.d.named_parameters()}
+            g_loss = tr._g_phase(6)
+            g_grads = {n: p.grad.clone() for n, p in tr.g.named_parameters()}
+            res.append((float(d_loss), float(gp), float(g_loss), d_grads, g_grads))
+    finally:
+        SelfAttention2d.fuse_projections = True
+    a, b = res
+    for k in range(3):
+        assert _close(a[k], b[k], 2e-5), (k, a[k], b[k])
+    for grads_a, grads_b in ((a[3], b[3]), (a[4], b[4])):
+        for n in grads_a:
+            scale = max(float(grads_b[n].abs().max()), 1e-3)
+            assert float((grads_a[n] - grads_b[n]).abs().max()) <= 3e-5 * scale + 2e-5, n

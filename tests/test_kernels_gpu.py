@@ -372,6 +372,27 @@ def test_conv_rejects_unsupported(K):
         K.conv2d_fwd(x, torch.zeros(4, 4, 5, 5).cuda(), None, None, torch.zeros(1, 4, 8, 8).cuda(), 1, 4, 4, 8, 8, 5)
 
 
+@pytest.mark.parametrize('shape', [(64, 32, 4, 4, 16, 64, 64), (128, 32, 4, 4, 16, 32, 32), (3, 32, 4, 4, 16, 8, 8), (2, 128, 16, 16, 64, 8, 8),
+                                   (5, 96, 12, 12, 48, 16, 16), (2, 20, 2, 2, 10, 12, 12), (2, 16, 2, 2, 8, 4, 4)])
+def test_fused_attention_projections(K, shape):
+    """tg_conv1x1_multi_{fwd,dgrad,wgrad}: theta | phi | g of SelfAttention2d in one pass each way, against three convolutions."""
+    B, Cin, c0, c1, c2, H, W = shape
+    assert K.conv1x1_multi_supported(c0, c1, c2, B, Cin, H, W)
+    C = c0 + c1 + c2
+    x, w = rnd(B, Cin, H, W), rnd(C, Cin, scale=0.2)
+    outs = [torch.zeros(B, c, H, W) for c in (c0, c1, c2)]
+    run_both(K, 'conv1x1_multi_fwd', [x, w, outs[0], outs[1], outs[2], c0, c1, c2, B, Cin, H, W], [2, 3, 4], tol=2e-5)
+    gys = [rnd(B, c, H, W, seed=3 + k) for k, c in enumerate((c0, c1, c2))]
+    run_both(K, 'conv1x1_multi_dgrad', [gys[0], gys[1], gys[2], w, torch.zeros(B, Cin, H, W), c0, c1, c2, B, Cin, H, W], [4], tol=3e-5)
+    ws = workspace(K.conv1x1_multi_wgrad_workspace(c0, c1, c2, B, Cin, H, W))
+    for acc in (0, 1):
+        run_both(K, 'conv1x1_multi_wgrad', [x, gys[0], gys[1], gys[2], rnd(C, Cin, seed=9), ws, ws.numel() * 4, c0, c1, c2, B, Cin, H, W, acc],
+                 [4], tol=5e-5, scratch=[5])
+    assert not K.conv1x1_multi_supported(c0, c1, c2, B, Cin, 5, 7)
+    with pytest.raises(RuntimeError):
+        K.conv1x1_multi_fwd(x.cuda()[:, :, :, :W - 1].contiguous(), w.cuda(), *[o.cuda() for o in outs], c0, c1, c2, B, Cin, H, W - 1)
+
+
 BN_SHAPES = [(4, 16, 64 * 64), (8, 128, 16), (3, 3, 32 * 32), (2, 32, 128 * 128), (5, 100, 8 * 8), (64, 128, 1), (2, 7, 12 * 10),
              (64, 128, 64), (64, 128, 256), (16, 64, 1024), (64, 128, 16)]
 
