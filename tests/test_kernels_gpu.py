@@ -388,9 +388,10 @@ def test_fused_attention_projections(K, shape):
     for acc in (0, 1):
         run_both(K, 'conv1x1_multi_wgrad', [x, gys[0], gys[1], gys[2], rnd(C, Cin, seed=9), ws, ws.numel() * 4, c0, c1, c2, B, Cin, H, W, acc],
                  [4], tol=5e-5, scratch=[5])
-    assert not K.conv1x1_multi_supported(c0, c1, c2, B, Cin, 5, 7)
+    assert not K.conv1x1_multi_supported(c0, c1, c2, B, Cin, 5, 7) and not K.conv1x1_multi_supported(c0, c1, c2, B, 200, H, W)
     with pytest.raises(RuntimeError):
-        K.conv1x1_multi_fwd(x.cuda()[:, :, :, :W - 1].contiguous(), w.cuda(), *[o.cuda() for o in outs], c0, c1, c2, B, Cin, H, W - 1)
+        K.conv1x1_multi_fwd(torch.zeros(B, Cin, 5, 7).cuda(), w.cuda(), *[torch.zeros(B, c, 5, 7).cuda() for c in (c0, c1, c2)],
+                            c0, c1, c2, B, Cin, 5, 7)
 
 
 BN_SHAPES = [(4, 16, 64 * 64), (8, 128, 16), (3, 3, 32 * 32), (2, 32, 128 * 128), (5, 100, 8 * 8), (64, 128, 1), (2, 7, 12 * 10),

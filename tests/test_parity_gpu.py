@@ -36,7 +36,12 @@ def hip_backend():
 # D's Adam step) spans 7.6e-4 relative over six oracle runs with 1e-7 input noise, and the 8-thread oracle already sits 6.3e-4
 # from the single-threaded reference fixture (tools/knife_edge.py): the knife edge of the batch-2 fixture survives at batch 8
 # for this loss alone, so only g_loss gets the wider bound.
-KNIFE_EDGE = {'c128a3_iqn_b4': 3e-4, 'c128a3_cnn_b256': {'g_loss': 2e-4}, 'c128big_cnn_b8': {'g_loss': 2e-3}}
+# c64a1_iqn_b64: gp (and d_loss, which contains it) moves in quanta with the rounding pattern -- LeakyReLU masks under R1 flipping: the
+# HIP trainer lands between 5e-7 and 1.8e-4 from the fixture over five runs with 1e-7 input noise, with the attention projections
+# fused or separate alike (tools/knife_edge_hip.py, profiles/r03_knife_edge_c64a1_iqn_b64.txt); the fixture's own images happen to
+# sit at +1.35e-4 with the fused kernels, +4.4e-5 with the separate ones.
+KNIFE_EDGE = {'c128a3_iqn_b4': 3e-4, 'c128a3_cnn_b256': {'g_loss': 2e-4}, 'c128big_cnn_b8': {'g_loss': 2e-3},
+              'c64a1_iqn_b64': {'gp': 3e-4, 'd_loss': 3e-4}}
 
 
 def _loss_tol(case, name, default=1e-4):
