@@ -35,6 +35,8 @@ class RngFeed:
         self.mode = 'record'
         self.cursor = 0
         self.key = None         # batch shape the plan was recorded for
+        self._spec = None       # (generator state before, after) a speculative draw of the next step's inputs
+        self._uploaded = None   # event behind the last host -> device copies of the staging buffers
 
     def _draw_cpu(self, kind, rows, cols):
         if kind == 'z':
@@ -76,15 +78,48 @@ class RngFeed:
             self.host.append(host.pin_memory() if buf.is_cuda else host)
         self.cursor = 0
 
-    def refill(self):
-        for (kind, rows, cols), buf, host in zip(self.plan, self.static, self.host):
+    def _draw_into_host(self):
+        for (kind, rows, cols), host in zip(self.plan, self.host):
             if self.world == 1:
                 # straight into the pinned staging buffer: ``torch.randn(r, c)`` is ``empty(r, c).normal_()`` and
                 # ``torch.rand(r, 1)`` is ``empty(r, 1).uniform_()`` -- the same values from the same generator state
                 host.normal_() if kind == 'z' else host.uniform_()
             else:
                 host.copy_(self._draw_cpu(kind, rows, cols))
+
+    def prefetch(self):
+        """Draw the NEXT step's inputs while the GPU is busy with this one -- invisibly.  The CPU generator is serial: 63 us per
+        (64, 256) latent, and a rank of an N-GPU run draws the GLOBAL tensors (N times that: ~1 ms per step at 8 GPUs), all of
+        it GPU idle time if done between a step's loss read-back and the next step's first launch.  So, after a step's work
+        has been launched: remember the generator state, draw the plan into the staging buffers, remember the state after,
+        and PUT THE GENERATOR BACK.  ``refill`` adopts the values only if the generator is still exactly where it was left
+        (then drawing now would produce the same values and end in the remembered state); if anything drew or re-seeded in
+        between -- a sampler's ``sample_z(4)``, ``torch.manual_seed`` -- those draws saw the untouched stream, the
+        speculation is dropped and the step draws as usual."""
+        self._spec = None
+        if not self.plan:
+            return
+        if self._uploaded is not None:
+            self._uploaded.synchronize()          # the staging buffers are free (the copies ran at the head of this step)
+        before = torch.get_rng_state()
+        self._draw_into_host()
+        after = torch.get_rng_state()
+        torch.set_rng_state(before)
+        self._spec = (before, after)
+
+    def refill(self):
+        spec, self._spec = self._spec, None
+        if spec is not None and torch.equal(torch.get_rng_state(), spec[0]):
+            torch.set_rng_state(spec[1])
+        else:
+            if self._uploaded is not None:
+                self._uploaded.synchronize()
+            self._draw_into_host()
+        for buf, host in zip(self.static, self.host):
             buf.copy_(host, non_blocking=True)
+        if self.static and self.static[0].is_cuda:
+            self._uploaded = torch.cuda.Event()
+            self._uploaded.record()
         self.cursor = 0
 
 

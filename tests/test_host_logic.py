@@ -555,3 +555,27 @@ def test_fused_attention_projections_equal_three_separate_convolutions(kind, sin
         for n in grads_a:
             scale = max(float(grads_b[n].abs().max()), 1e-3)
             assert float((grads_a[n] - grads_b[n]).abs().max()) <= 3e-5 * scale + 2e-5, n
+
+
+def test_speculative_rng_prefetch_is_invisible():
+    """RngFeed.prefetch draws the next step's inputs early and puts the generator back: a run whose steps are separated by
+    nothing, by a foreign draw, or by a re-seed consumes the default generator exactly like a run that never speculates."""
+    cfg = GAN_CONFIGS['32']._replace(attention=())
+    imgs = synthetic_images(4, 32, 3)
+
+    def run(prefetch):
+        tr = IQNTrainer(IQNTrainer.default_args(config=cfg, batch_size=4, device='cpu', prefetch_rng=prefetch))
+        torch.manual_seed(0)
+        tr.build_models()
+        torch.manual_seed(21)
+        out = [tr.train_batch(imgs), tr.train_batch(imgs)]        # back to back: the speculation is adopted
+        assert (tr.rng_feed._spec is not None) == prefetch
+        out.append(float(torch.randn(3).sum()))                    # a foreign draw between steps sees the untouched stream ...
+        out.append(tr.train_batch(imgs))                           # ... and the step after it draws afresh
+        torch.manual_seed(77)                                      # a re-seed between steps
+        out.append(tr.train_batch(imgs))
+        out.append(tr.train_batch(imgs))
+        out.append(float(torch.rand(1)))
+        return out
+
+    assert run(True) == run(False)
