@@ -27,6 +27,9 @@ from .trainer import Trainer
 from .utils import toggle_grad
 
 
+_PREFETCH_RNG = __import__('os').environ.get('TG_PREFETCH_RNG', '1') != '0'      # (development knob; args.prefetch_rng overrides)
+
+
 class CNNTrainer(Trainer):
     discriminator_class = Discriminator
     d_output_class = DiscriminatorOutput
@@ -276,7 +279,7 @@ class CNNTrainer(Trainer):
         self.steps += 1
         if not torch.is_tensor(vals):
             vals = torch.stack([v for v in vals if v is not None])
-        if feed.mode == 'serve' and restore is None and getattr(self.args, 'prefetch_rng', True):
+        if feed.mode == 'serve' and restore is None and getattr(self.args, 'prefetch_rng', _PREFETCH_RNG):
             feed.prefetch()          # the next step's latents, drawn under this step's GPU time (see RngFeed.prefetch)
         vals = self._read_back(vals)                                         # one device->host read
         return dict(g_loss=vals[0], d_loss=vals[1], gp=vals[2] if len(vals) > 2 else 0.)
