@@ -87,7 +87,9 @@ class KernelTimer:
                      'maxpool2_fwd', 'maxpool2_bwd', 'scale_add_dev', 'dot', 'scale_dev', 'mul', 'lrelu_bwd', 'tanh_fwd', 'tanh_bwd',
                      'row_sum', 'row_bcast', 'bce_logits', 'sumsq', 'fill', 'scale', 'channel_bcast', 'conv2d_wgrad_partials',
                      'conv2d_wgrad_reduce_batch', 'upconv3x3_fwd', 'upconv3x3_weights', 'upconv3x3_dgrad', 'upconv3x3_wgrad',
-                     'upconv3x3_weights_t', 'poolconv3x3_fwd', 'poolconv3x3_dgrad', 'poolconv3x3_wgrad', 'poolconv3x3_weights'):
+                     'upconv3x3_weights_t', 'poolconv3x3_fwd', 'poolconv3x3_dgrad', 'poolconv3x3_wgrad', 'poolconv3x3_weights',
+                     'bn_train_fwd_groups', 'bn_act_bwd_groups', 'copy_channels', 'conv1x1_multi_fwd', 'conv1x1_multi_dgrad',
+                     'conv1x1_multi_wgrad', 'add4', 'maxpool2_gather', 'repeat_rows', 'sum_reps', 'iqn_loss', 'iqn_cos_embed'):
             fn = getattr(self.K, name)
             self._saved[name] = fn
             setattr(self.K, name, self._wrap(name, fn))
