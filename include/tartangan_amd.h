@@ -104,7 +104,7 @@ int tg_conv2d_wgrad(const float* x, const float* gy, float* gw, float* gbias /*n
  * as ONE pass each way: x is read once for the three outputs, the three output gradients give the input gradient in one pass
  * (no three-way add) and the three filter gradients in one pass.  w / gw: the three filters back to back,
  * [c0 + c1 + c2][Cin] (they are adjacent in the parameter bucket); y_k / gy_k: (B, c_k, H, W) each.  Bandwidth-bound
- * streaming kernels (no LDS); need H*W % 16 == 0, at most 128 channels either side, 16-byte aligned tensors. */
+ * streaming kernels (no LDS); need H*W % 16 == 0, at most 64 channels either side, 16-byte aligned tensors. */
 int tg_conv1x1_multi_supported(int c0, int c1, int c2, int B, int Cin, int H, int W);
 int tg_conv1x1_multi_fwd(const float* x, const float* w, float* y0, float* y1, float* y2, int c0, int c1, int c2,
                          int B, int Cin, int H, int W, void* stream);

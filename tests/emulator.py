@@ -124,7 +124,7 @@ class Emulator:
 
     # theta | phi | g of SelfAttention2d as one pass: the three 1x1 convolutions, their joint input gradient, their filter gradients
     def conv1x1_multi_supported(self, c0, c1, c2, B, Cin, H, W):
-        return int((H * W) % 16 == 0 and c0 + c1 + c2 <= 128 and Cin <= 128)
+        return int((H * W) % 16 == 0 and c0 + c1 + c2 <= 64 and Cin <= 64)
 
     def conv1x1_multi_fwd(self, x, w, y0, y1, y2, c0, c1, c2, B, Cin, H, W):
         r = F.conv2d(_v(x, B, Cin, H, W), _v(w, c0 + c1 + c2, Cin, 1, 1))

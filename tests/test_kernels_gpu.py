@@ -372,8 +372,8 @@ def test_conv_rejects_unsupported(K):
         K.conv2d_fwd(x, torch.zeros(4, 4, 5, 5).cuda(), None, None, torch.zeros(1, 4, 8, 8).cuda(), 1, 4, 4, 8, 8, 5)
 
 
-@pytest.mark.parametrize('shape', [(64, 32, 4, 4, 16, 64, 64), (128, 32, 4, 4, 16, 32, 32), (3, 32, 4, 4, 16, 8, 8), (2, 128, 16, 16, 64, 8, 8),
-                                   (5, 96, 12, 12, 48, 16, 16), (2, 20, 2, 2, 10, 12, 12), (2, 16, 2, 2, 8, 4, 4)])
+@pytest.mark.parametrize('shape', [(64, 32, 4, 4, 16, 64, 64), (128, 32, 4, 4, 16, 32, 32), (3, 32, 4, 4, 16, 8, 8), (2, 64, 8, 8, 32, 8, 8),
+                                   (5, 48, 6, 6, 24, 16, 16), (2, 20, 2, 2, 10, 12, 12), (2, 16, 2, 2, 8, 4, 4)])
 def test_fused_attention_projections(K, shape):
     """tg_conv1x1_multi_{fwd,dgrad,wgrad}: theta | phi | g of SelfAttention2d in one pass each way, against three convolutions."""
     B, Cin, c0, c1, c2, H, W = shape
@@ -388,7 +388,7 @@ def test_fused_attention_projections(K, shape):
     for acc in (0, 1):
         run_both(K, 'conv1x1_multi_wgrad', [x, gys[0], gys[1], gys[2], rnd(C, Cin, seed=9), ws, ws.numel() * 4, c0, c1, c2, B, Cin, H, W, acc],
                  [4], tol=5e-5, scratch=[5])
-    assert not K.conv1x1_multi_supported(c0, c1, c2, B, Cin, 5, 7) and not K.conv1x1_multi_supported(c0, c1, c2, B, 200, H, W)
+    assert not K.conv1x1_multi_supported(c0, c1, c2, B, Cin, 5, 7) and not K.conv1x1_multi_supported(c0, c1, c2, B, 128, H, W)
     with pytest.raises(RuntimeError):
         K.conv1x1_multi_fwd(torch.zeros(B, Cin, 5, 7).cuda(), w.cuda(), *[torch.zeros(B, c, 5, 7).cuda() for c in (c0, c1, c2)],
                             c0, c1, c2, B, Cin, 5, 7)
