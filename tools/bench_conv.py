@@ -8,7 +8,7 @@ K = backend.get()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 SHAPES = [  # Cin, Cout, H, ks
     (128, 128, 8, 3), (128, 128, 16, 3), (128, 64, 32, 3), (64, 64, 32, 3), (64, 32, 64, 3), (32, 32, 64, 3),
-    (32, 16, 128, 3), (16, 16, 128, 3), (16, 32, 64, 3), (32, 64, 32, 3), (64, 128, 16, 3), (128, 128, 4, 3),
+    (32, 16, 128, 3), (16, 16, 128, 3), (16, 32, 64, 3), (32, 64, 32, 3), (64, 128, 16, 3), (128, 128, 4, 3), (4, 16, 128, 3),
     (3, 16, 128, 1), (16, 3, 128, 1), (32, 16, 128, 1), (64, 32, 64, 1), (128, 64, 32, 1), (16, 32, 64, 1), (32, 4, 64, 1), (32, 16, 64, 1), (16, 32, 64, 1),
 ]
 def timeit(fn, iters=20):
