@@ -308,7 +308,19 @@ class _Paired(Function):
         # made in here has no history), or the R1 penalty's second derivative through that input would be lost.
         ctx.from_input = [None if t is None else joined.get(id(t)) for t in rec.saved_tensors]
         ctx.n_halves = len(reals)
-        ctx.save_for_backward(*rec.saved_tensors, *reals, *fakes)
+        flat, out_at = [], {}
+        for kind, o in zip(kinds, outs):
+            if kind == 'b':
+                n = o.shape[0] // 2
+                out_at[id(o)] = len(flat)
+                flat += [o[:n], o[n:]]
+            else:
+                flat.append(o)
+        # Likewise a saved tensor that IS a batch output (tanh keeps y): its halves are saved as outputs of THIS node, so the
+        # single-half backward differentiates through them.
+        ctx.from_output = [None if t is None else out_at.get(id(t)) for t in rec.saved_tensors]
+        ctx.out_keep = sorted({at for at in ctx.from_output if at is not None})
+        ctx.save_for_backward(*rec.saved_tensors, *reals, *fakes, *[flat[at + k] for at in ctx.out_keep for k in (0, 1)])
         ctx.F, ctx.kinds, ctx.materialize = F, kinds, rec.materialize
         ctx.attrs = {k: v for k, v in vars(rec).items() if k not in ('saved_tensors', 'materialize', 'needs_input_grad')}
         if 'data_input' in ctx.attrs:
@@ -316,13 +328,6 @@ class _Paired(Function):
             pos0 = sum(2 if k == 'b' else 1 for k in layout[:first])
             ctx.attrs['data_input'] = is_data(args[pos0]) and is_data(args[pos0 + 1])
         ctx.set_materialize_grads(False)
-        flat = []
-        for kind, o in zip(kinds, outs):
-            if kind == 'b':
-                n = o.shape[0] // 2
-                flat += [o[:n], o[n:]]
-            else:
-                flat.append(o)
         ctx.out_meta = [(tuple(o.shape), o.dtype) for o in flat]
         return tuple(flat)
 
@@ -359,7 +364,8 @@ class _Paired(Function):
         n_saved = len(ctx.from_input)
         saved = ctx.saved_tensors[:n_saved]
         reals = ctx.saved_tensors[n_saved:n_saved + ctx.n_halves]
-        fakes = ctx.saved_tensors[n_saved + ctx.n_halves:]
+        fakes = ctx.saved_tensors[n_saved + ctx.n_halves:n_saved + 2 * ctx.n_halves]
+        kept = ctx.saved_tensors[n_saved + 2 * ctx.n_halves:]
         device = next(g for g in gouts if g is not None).device
 
         def zeros(at):
@@ -373,8 +379,13 @@ class _Paired(Function):
             def view(t):                    # this half's rows of a saved tensor (statistics: this group's entries)
                 n = t.shape[0] // 2
                 return t[:n] if half else t[n:]
-            sub.saved_tensors = tuple(own[j] if j is not None else (view(t) if (k == 'h' and t is not None) else t)
-                                      for k, t, j in zip(saved_spec, saved, ctx.from_input))
+            own_out = {at: kept[2 * i + (0 if half else 1)] for i, at in enumerate(ctx.out_keep)}
+            sub.saved_tensors = tuple(own[j] if j is not None else own_out[o] if o is not None
+                                      else (view(t) if (k == 'h' and t is not None) else t)
+                                      for k, t, j, o in zip(saved_spec, saved, ctx.from_input, ctx.from_output))
+            if getattr(sub, '_out_meta', None):          # (what the base wrapper zero-fills missing gradients from: B rows here)
+                sub._out_meta = [m if (m is None or kind != 'b') else ((m[0][0] // 2,) + tuple(m[0][1:]), m[1], m[2])
+                                 for kind, m in zip(kinds, sub._out_meta)]
             if hasattr(F, 'pair_half'):
                 F.pair_half(sub)
             for kind, g, gf, at in groups:
