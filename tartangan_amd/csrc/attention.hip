@@ -71,21 +71,30 @@ template <int D, int DV> struct AttnDims {
   static constexpr int VS = (DV + 3) / 4;      // k-steps of a contraction over dv
 };
 constexpr int JT = 4;                          // 16-row tiles of the streamed side per loop iteration (forward, dtheta)
-constexpr int JK = 2;                          // ... for dphi / dg, whose per-tile operand set is larger
+constexpr int JK2 = 2;                         // ... for dphi / dg, whose per-tile operand set is larger
 
 // A wave owns RT 16-row tiles of its side (RT = 4 when that still leaves >= 4 waves per SIMD, else 1) and reuses every
 // streamed operand it loaded for all of them: with RT = 1 the 64x64-pixel attention map of the generator re-read K / V
 // (or Q / dO) from L2 once per 16 rows -- 1.4 GB per call -- and ran at a third of the matrix-core rate.
 
 // ---------------------------------------------------------------------------------------------------- forward
-// One step = 64 keys: per owned query tile 4 score tiles, ONE running-max update / accumulator rescale, 16 exp2 and the
-// PV products alternating between two accumulators (halves the dependent-MFMA chain).  Scores are kept in log2 units
-// (theta is scaled by log2 e on load) so that the softmax weights are bare v_exp_f32.
+// One step = 64 keys: per owned query tile 4 score tiles, 16 exp2 and the PV products alternating between two accumulators
+// (halves the dependent-MFMA chain).  Scores are kept in log2 units (theta is scaled by log2 e on load) so that the softmax
+// weights are bare v_exp_f32, and RELATIVE to a per-query reference value ref (the score tiles start from -ref in the MFMA's C
+// operand: no subtraction per element).  softmax is invariant under the choice of ref, so ref need not be the running
+// maximum: it starts as the maximum over the first 16 keys and is raised -- accumulators and partial sum rescaled -- only
+// when some score of the wave exceeds it by more than SLACK (weights stay below 2^SLACK: no overflow; ref is always a score
+// of the row, so the largest weight of a row is >= 1: no underflow of the sum).  On the generator's 64x64 map that is a
+// handful of rescales per row instead of one per 64 keys, each of which dragged the 32 accumulator registers through the
+// vector ALU and two cross-lane maxima through the LDS crossbar.
+constexpr float SLACK = 10.f;
+
 template <int D, int DV, int RT, bool FULL>
 __device__ __forceinline__ void fwd_step(const float* __restrict__ pb, const float* __restrict__ gb, const float (&qB)[RT][(D + 3) / 4],
-                                         f32x4 (&acc)[RT][2][(DV + 15) / 16], float (&mx)[RT], float (&lpart)[RT], int k0, int M,
+                                         f32x4 (&acc)[RT][RT == 4 ? 1 : 2][(DV + 15) / 16], float (&ref)[RT], float (&lpart)[RT], int k0, int M,
                                          int c, int g) {
   using A = AttnDims<D, DV>;
+  constexpr int NA = RT == 4 ? 1 : 2;          // accumulators per query tile: a wave that owns 4 tiles has chains enough
   float kA[JT][A::KS];
   f32x4 vA[JT][A::VT];
 #pragma unroll
@@ -98,13 +107,14 @@ __device__ __forceinline__ void fwd_step(const float* __restrict__ pb, const flo
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
     f32x4 st[JT];
-    float tmax = -INFINITY;
+    const float nr = -ref[q];
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
-      st[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      st[j] = f32x4{nr, nr, nr, nr};
 #pragma unroll
       for (int s = 0; s < A::KS; ++s) st[j] = mfma16(kA[j][s], qB[q][s], st[j]);
     }
+    float tmax = -INFINITY;
 #pragma unroll
     for (int j = 0; j < JT; ++j)
 #pragma unroll
@@ -112,34 +122,48 @@ __device__ __forceinline__ void fwd_step(const float* __restrict__ pb, const flo
         if (!FULL && k0 + 16 * j + 4 * g + r >= M) st[j][r] = -INFINITY;
         tmax = fmaxf(tmax, st[j][r]);
       }
-    const float mnew = fmaxf(mx[q], group_max(tmax));
-    const float resc = fast_exp2(mx[q] - mnew);             // 2^-inf = 0 on the first step
-    mx[q] = mnew;
+    if (__builtin_amdgcn_ballot_w64(tmax > SLACK) != 0) {        // wave-uniform, rare after the first steps
+      const float up = fmaxf(group_max(tmax), 0.f);              // the same for the 4 lane groups of a query
+      const float resc = fast_exp2(-up);
+      ref[q] += up;
+      lpart[q] *= resc;
+#pragma unroll
+      for (int t = 0; t < A::VT; ++t)
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[q][a][t] *= resc;
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[j][r] -= up;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int j = 0; j < JT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        st[j][r] = fast_exp2(st[j][r] - mnew);
+        st[j][r] = fast_exp2(st[j][r]);
         psum += st[j][r];
       }
-    lpart[q] = lpart[q] * resc + psum;
+    lpart[q] += psum;
 #pragma unroll
-    for (int t = 0; t < A::VT; ++t) {
-      acc[q][0][t] *= resc;
-      acc[q][1][t] *= resc;
+    for (int t = 0; t < A::VT; ++t)
 #pragma unroll
       for (int j = 0; j < JT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[q][j & 1][t] = mfma16(vA[j][t][r], st[j][r], acc[q][j & 1][t]);
-    }
+        for (int r = 0; r < 4; ++r) acc[q][j % NA][t] = mfma16(vA[j][t][r], st[j][r], acc[q][j % NA][t]);
   }
 }
 
+// registers per lane (vector + accumulator file) that leave room for W waves per SIMD
+template <int D, int DV, int RT> struct AttnOcc {
+  // the generator's 64x64 map at batch 64 is 4096 waves of 64 queries: 4 per SIMD, resident at once only within 128 registers
+  static constexpr int WAVES = (RT == 4 && D <= 4) ? 4 : 1;
+};
+
 template <int D, int DV, int RT>
-__global__ void __launch_bounds__(AT) attn_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
-                                                      const float* __restrict__ g_, float* __restrict__ o, float* __restrict__ lse,
-                                                      int N, int M, int vecM) {
+__global__ void __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(AttnOcc<D, DV, RT>::WAVES)))
+attn_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi, const float* __restrict__ g_, float* __restrict__ o,
+                float* __restrict__ lse, int N, int M, int vecM) {
   using A = AttnDims<D, DV>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -149,21 +173,34 @@ __global__ void __launch_bounds__(AT) attn_fwd_kernel(const float* __restrict__ 
   const float* th = theta + (int64_t)b * D * N;
   const float* pb = phi + (int64_t)b * D * M;
   const float* gb = g_ + (int64_t)b * DV * M;
-  float qB[RT][A::KS], mx[RT], lpart[RT];
-  f32x4 acc[RT][2][A::VT];
+  constexpr int NA = RT == 4 ? 1 : 2;
+  float qB[RT][A::KS], ref[RT], lpart[RT];
+  f32x4 acc[RT][NA][A::VT];
+  float k0A[A::KS];                                         // the first 16 keys: where the reference values come from
+#pragma unroll
+  for (int s = 0; s < A::KS; ++s) k0A[s] = ld1<false>(pb, 4 * s + g, D, M, c, M);
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
 #pragma unroll
     for (int s = 0; s < A::KS; ++s) qB[q][s] = ld1<false>(th, 4 * s + g, D, N, q0 + 16 * q + c, N) * LOG2E;
 #pragma unroll
-    for (int t = 0; t < A::VT; ++t) acc[q][0][t] = acc[q][1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mx[q] = -INFINITY;
+    for (int t = 0; t < A::VT; ++t)
+#pragma unroll
+      for (int a = 0; a < NA; ++a) acc[q][a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < A::KS; ++s) s0 = mfma16(k0A[s], qB[q][s], s0);
+    float m0 = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * g + r < M) m0 = fmaxf(m0, s0[r]);
+    ref[q] = group_max(m0);
     lpart[q] = 0.f;
   }
   int k0 = 0;
   if (vecM)
-    for (; k0 + 16 * JT <= M; k0 += 16 * JT) fwd_step<D, DV, RT, true>(pb, gb, qB, acc, mx, lpart, k0, M, c, g);
-  for (; k0 < M; k0 += 16 * JT) fwd_step<D, DV, RT, false>(pb, gb, qB, acc, mx, lpart, k0, M, c, g);
+    for (; k0 + 16 * JT <= M; k0 += 16 * JT) fwd_step<D, DV, RT, true>(pb, gb, qB, acc, ref, lpart, k0, M, c, g);
+  for (; k0 < M; k0 += 16 * JT) fwd_step<D, DV, RT, false>(pb, gb, qB, acc, ref, lpart, k0, M, c, g);
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
     const float l = group_sum(lpart[q]);
@@ -176,9 +213,9 @@ __global__ void __launch_bounds__(AT) attn_fwd_kernel(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int dv = 16 * t + 4 * g + r;
-          if (dv < DV) ob[(int64_t)dv * N] = (acc[q][0][t][r] + acc[q][1][t][r]) * inv;
+          if (dv < DV) ob[(int64_t)dv * N] = (acc[q][0][t][r] + (NA == 2 ? acc[q][NA - 1][t][r] : 0.f)) * inv;
         }
-      if (g == 0) lse[(int64_t)b * N + n] = (mx[q] + __log2f(l)) * LN2;
+      if (g == 0) lse[(int64_t)b * N + n] = (ref[q] + __log2f(l)) * LN2;
     }
   }
 }
@@ -201,8 +238,9 @@ __global__ void __launch_bounds__(AT) attn_delta_kernel(const float* __restrict_
 template <int D, int DV, int RT, bool FULL>
 __device__ __forceinline__ void bwd_q_step(const float* __restrict__ pb, const float* __restrict__ gb, const float (&qB)[RT][(D + 3) / 4],
                                            const float (&doB)[RT][(DV + 3) / 4], const float (&L2)[RT], const float (&dl)[RT],
-                                           f32x4 (&dq)[RT][2], int k0, int M, int c, int g) {
+                                           f32x4 (&dq)[RT][RT == 4 ? 1 : 2], int k0, int M, int c, int g) {
   using A = AttnDims<D, DV>;
+  constexpr int NA = RT == 4 ? 1 : 2;
   float kA[JT][A::KS], vK[JT][A::VS];
   f32x4 kT[JT];
 #pragma unroll
@@ -225,13 +263,13 @@ __device__ __forceinline__ void bwd_q_step(const float* __restrict__ pb, const f
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = (!FULL && k0 + 16 * j + 4 * g + r >= M) ? 0.f : fast_exp2(st[r] - L2[q]);
-        dq[q][j & 1] = mfma16(kT[j][r], p * (dp[r] - dl[q]), dq[q][j & 1]);             // dtheta^T[d 4g+r'][query c]
+        dq[q][j % NA] = mfma16(kT[j][r], p * (dp[r] - dl[q]), dq[q][j % NA]);             // dtheta^T[d 4g+r'][query c]
       }
     }
 }
 
 template <int D, int DV, int RT>
-__global__ void __launch_bounds__(AT) attn_bwd_q_kernel(const float* __restrict__ go, const float* __restrict__ theta,
+__global__ void __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(AttnOcc<D, DV, RT>::WAVES))) attn_bwd_q_kernel(const float* __restrict__ go, const float* __restrict__ theta,
                                                         const float* __restrict__ phi, const float* __restrict__ g_,
                                                         const float* __restrict__ lse, const float* __restrict__ delta,
                                                         float* __restrict__ dtheta, int N, int M, int vecM) {
@@ -247,7 +285,8 @@ __global__ void __launch_bounds__(AT) attn_bwd_q_kernel(const float* __restrict_
   const float* gb = g_ + (int64_t)b * DV * M;
   const float* gob = go + (int64_t)b * DV * N;
   float qB[RT][A::KS], doB[RT][A::VS], L2[RT], dl[RT];
-  f32x4 dq[RT][2];
+  constexpr int NA = RT == 4 ? 1 : 2;
+  f32x4 dq[RT][NA];
 #pragma unroll
   for (int q = 0; q < RT; ++q) {
     const int n = q0 + 16 * q + c;
@@ -257,7 +296,8 @@ __global__ void __launch_bounds__(AT) attn_bwd_q_kernel(const float* __restrict_
     for (int u = 0; u < A::VS; ++u) doB[q][u] = ld1<false>(gob, 4 * u + g, DV, N, n, N);      // dO^T[dv 4u+g][query c]
     L2[q] = n < N ? lse[(int64_t)b * N + n] * LOG2E : INFINITY;                               // dead query: p = 0
     dl[q] = n < N ? delta[(int64_t)b * N + n] : 0.f;
-    dq[q][0] = dq[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < NA; ++a) dq[q][a] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   int k0 = 0;
   if (vecM)
@@ -270,7 +310,7 @@ __global__ void __launch_bounds__(AT) attn_bwd_q_kernel(const float* __restrict_
       float* dt = dtheta + (int64_t)b * D * N + n;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * g + r < D) dt[(int64_t)(4 * g + r) * N] = dq[q][0][r] + dq[q][1][r];
+        if (4 * g + r < D) dt[(int64_t)(4 * g + r) * N] = dq[q][0][r] + (NA == 2 ? dq[q][NA - 1][r] : 0.f);
     }
   }
 }
@@ -283,6 +323,7 @@ __device__ __forceinline__ void bwd_k_step(const float* __restrict__ th, const f
                                            const float (&vB)[RT][(DV + 3) / 4], f32x4 (&dk)[RT], f32x4 (&dv_)[RT][(DV + 15) / 16],
                                            int n0, int N, int c, int g) {
   using A = AttnDims<D, DV>;
+  constexpr int JK = RT == 4 ? 1 : JK2;          // a wave that owns 4 key tiles streams one query tile at a time (registers)
   float qA[JK][A::KS], goA[JK][A::VS];
   f32x4 L4[JK], d4[JK], qT[JK], goT[JK][A::VT];
 #pragma unroll
@@ -318,7 +359,7 @@ __device__ __forceinline__ void bwd_k_step(const float* __restrict__ th, const f
 }
 
 template <int D, int DV, int RT>
-__global__ void __launch_bounds__(AT) attn_bwd_k_kernel(const float* __restrict__ go, const float* __restrict__ theta,
+__global__ void __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(AttnOcc<D, DV, RT>::WAVES))) attn_bwd_k_kernel(const float* __restrict__ go, const float* __restrict__ theta,
                                                         const float* __restrict__ phi, const float* __restrict__ g_,
                                                         const float* __restrict__ lse, const float* __restrict__ delta,
                                                         float* __restrict__ dphi, float* __restrict__ dg, int N, int M, int QS,
@@ -350,8 +391,9 @@ __global__ void __launch_bounds__(AT) attn_bwd_k_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < A::VT; ++t) dv_[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  constexpr int JK = RT == 4 ? 1 : JK2;
   const int slice = blockIdx.z;
-  const int per = ((N + QS - 1) / QS + 16 * JK - 1) / (16 * JK) * (16 * JK);
+  const int per = ((N + QS - 1) / QS + 16 * JK2 - 1) / (16 * JK2) * (16 * JK2);
   const int n_begin = slice * per, n_end = min(N, n_begin + per);
   int n0 = n_begin;
   if (vecN)
@@ -391,7 +433,7 @@ static inline int attn_qsplit(int B, int N, int M) {
   const int64_t base1 = (int64_t)((M + 15) / 16) * B, base4 = (int64_t)((M + 63) / 64) * B;   // waves at QS = 1 for RT = 1 / 4
   const int64_t base = base4 >= 1024 ? base4 : base1;
   int qs = (int)((4096 + base - 1) / base);
-  const int maxqs = (N + 16 * JK - 1) / (16 * JK);
+  const int maxqs = (N + 16 * JK2 - 1) / (16 * JK2);
   if (qs > maxqs) qs = maxqs;
   if (qs > 16) qs = 16;
   if (qs < 1) qs = 1;

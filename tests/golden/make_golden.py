@@ -117,6 +117,8 @@ CASES = {
     'c128big_cnn_b8': ('128big', 'cnn', 8, 1),
     # BASELINE.json config 4 at its GLOBAL batch (256 = 8 GPUs x 32; replayed as 4 ranks x 64 with SyncBN on one GPU)
     'c128a3_cnn_b256': ('128:3', 'cnn', 256, 1),
+    # BASELINE.json config 5 at its GLOBAL batch (512 = 8 GPUs x 64; replayed as 4 ranks x 128 with SyncBN on one GPU)
+    'c128a3_iqn_b512': ('128:3', 'iqn', 512, 1),
 }
 
 WEIGHT_SEED = 7

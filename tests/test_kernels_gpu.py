@@ -614,6 +614,20 @@ def test_fused_attention(K, dims):
                              ws, B, D, DV, N, M], [6, 7, 8], tol=2e-5)
 
 
+@pytest.mark.parametrize('dims', [(3, 4, 16, 1024, 256), (256, 4, 16, 1024, 256), (2, 16, 64, 256, 64), (260, 1, 4, 1020, 255)])
+def test_fused_attention_wide_score_range(K, dims):
+    """The forward kernel keeps a per-query reference score that it raises lazily (only past a slack): keys whose scores
+    keep growing along the row force many raises, and a large common negative offset would underflow a reference that is
+    not a score of the row."""
+    B, D, DV, N, M = dims
+    ramp = torch.linspace(0.1, 3.0, M)
+    theta, phi, g = rnd(B, D, N) * 4, rnd(B, D, M, seed=1) * 4 * ramp, rnd(B, DV, M, seed=2)
+    theta[:, 0, :] = -40.
+    phi[:, 0, :] = 8. + 0.01 * ramp                    # every score carries about -320
+    o, lse = torch.zeros(B, DV, N), torch.zeros(B, N)
+    run_both(K, 'attn_fwd', [theta, phi, g, o, lse, B, D, DV, N, M], [3, 4], tol=2e-4)      # (NaN / inf fail the comparison)
+
+
 @pytest.mark.parametrize('shape', [(3 * 1024, 256), (2 * 300, 75), (70, 1024), (5, 6)])
 def test_attention_second_order_rows(K, shape):
     """The row-wise middle of the differentiated attention backward; every output overwrites an input."""
