@@ -111,7 +111,8 @@ def test_sync_bn_ranks_reproduce_the_reference_fixture_at_the_global_batch(case,
     """BASELINE.json configs 4 / 5 at the benched model: the REFERENCE's own step (128:3, fixtures written by its CNNTrainer /
     IQNTrainer) reproduced by several ranks with synchronised BatchNorm -- global z / tau streams sliced per rank, images
     sharded, gradients averaged.  Batch 64 as two ranks of 32, and **config 4 at its real global batch: 256 images as four
-    ranks of 64** (the per-GPU batch of the bench; on hardware it is eight ranks of 32).  1e-4 on the three losses, like one GPU."""
+    ranks of 64** (the per-GPU batch of the bench; on hardware it is eight ranks of 32).  1e-4 on the three losses (g_loss of the
+    batch-256 fixture: its measured knife-edge bound), like one GPU."""
     from conftest import load_golden
     fx = load_golden(case)
     assert fx['batch'] in (64, 256) and fx.get('flags', {}) == {}
@@ -120,6 +121,7 @@ def test_sync_bn_ranks_reproduce_the_reference_fixture_at_the_global_batch(case,
     res = _run(fx['trainer'], 'sync_bn', 1, global_batch=fx['batch'], world=world, config=fx['config'], attention=fx['attention'],
                size=fx['size'], img_seed=fx['img_seed'])
     assert res['replicas_equal']
+    from test_parity_gpu import _loss_tol          # (the documented knife edges: the same bounds as on one GPU)
     for got, name in zip(res['losses'][0], ('g_loss', 'd_loss', 'gp')):
         want = fx['steps'][0][name]
-        assert abs(got - want) <= 1e-4 * max(abs(want), 1e-6), (case, name, got, want)
+        assert abs(got - want) <= _loss_tol(case, name) * max(abs(want), 1e-6), (case, name, got, want)
