@@ -81,13 +81,17 @@ int tg_poolconv3x3_dgrad(const float* gy, const float* wp, float* gx, int B, int
 /* Weight gradients of the two stride-2 forms (convolution_backward grad_weight of the 3x3 filter, deterministic):
  * both are T[o][i][u][v] = sum lo[o][r][c] * hi[i][2r-1+u][2c-1+v] folded back onto the 3x3 taps -- 16 products per
  * low-resolution pixel instead of 36 on the materialised high-resolution pair.  (B, ., H, W) is the LOW-resolution
- * plane; where the plane is smaller than 16 x 16 they return TG_EUNSUPPORTED and the caller uses tg_conv2d_wgrad. */
+ * plane; where the plane is smaller than 16 x 16 they return TG_EUNSUPPORTED and the caller uses tg_conv2d_wgrad.
+ * gbias (nullable, Cout floats): the bias gradient sum_{b,h,w} gy, taken from the operands these kernels stage anyway
+ * (convolution_backward's grad_bias; `accumulate` applies to it as to gw).                                          */
 size_t tg_poolconv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W);
 int tg_poolconv3x3_wgrad(const float* x /*(B,Cin,2H,2W)*/, const float* gy /*(B,Cout,H,W)*/, float* gw, float* workspace,
-                         size_t workspace_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
+                         size_t workspace_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, float* gbias /*nullable*/,
+                         void* stream);
 size_t tg_upconv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W);
 int tg_upconv3x3_wgrad(const float* a /*(B,Cin,H,W)*/, const float* gy /*(B,Cout,2H,2W)*/, float* gw, float* workspace,
-                       size_t workspace_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, void* stream);
+                       size_t workspace_bytes, int B, int Cin, int Cout, int H, int W, int accumulate, float* gbias /*nullable*/,
+                       void* stream);
 /* gx = d/dx: correlation of gy with the transposed, spatially flipped filter
  * (what autograd's convolution_backward computes for grad_input)              */
 int tg_conv2d_dgrad(const float* gy, const float* w, float* gx,

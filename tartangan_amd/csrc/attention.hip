@@ -220,19 +220,6 @@ attn_fwd_kernel(const float* __restrict__ theta, const float* __restrict__ phi, 
   }
 }
 
-// delta[n] = sum_v go[v][n] * o[v][n]
-__global__ void __launch_bounds__(AT) attn_delta_kernel(const float* __restrict__ go, const float* __restrict__ o,
-                                                        float* __restrict__ delta, int DV, int N) {
-  const int b = blockIdx.y;
-  const int n = blockIdx.x * AT + threadIdx.x;
-  if (n >= N) return;
-  const float* a = go + (int64_t)b * DV * N;
-  const float* c = o + (int64_t)b * DV * N;
-  float acc = 0.f;
-  for (int v = 0; v < DV; ++v) acc = fmaf(a[(int64_t)v * N + n], c[(int64_t)v * N + n], acc);
-  delta[(int64_t)b * N + n] = acc;
-}
-
 // ---------------------------------------------------------------------------------------------------- dtheta
 // query-owned: dtheta[d][n] = sum_k ds(n,k) phi[d][k],  ds = p (dp - delta), p = exp(s - lse), dp = go_n . g_k
 template <int D, int DV, int RT, bool FULL>
@@ -271,7 +258,8 @@ __device__ __forceinline__ void bwd_q_step(const float* __restrict__ pb, const f
 template <int D, int DV, int RT>
 __global__ void __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(AttnOcc<D, DV, RT>::WAVES))) attn_bwd_q_kernel(const float* __restrict__ go, const float* __restrict__ theta,
                                                         const float* __restrict__ phi, const float* __restrict__ g_,
-                                                        const float* __restrict__ lse, const float* __restrict__ delta,
+                                                        const float* __restrict__ o, const float* __restrict__ lse,
+                                                        float* __restrict__ delta /*out: sum_v go o per query, for the key-owned kernel*/,
                                                         float* __restrict__ dtheta, int N, int M, int vecM) {
   using A = AttnDims<D, DV>;
   static_assert(D <= 16, "one 16-row tile of dtheta");
@@ -284,6 +272,7 @@ __global__ void __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(AttnOcc
   const float* pb = phi + (int64_t)b * D * M;
   const float* gb = g_ + (int64_t)b * DV * M;
   const float* gob = go + (int64_t)b * DV * N;
+  const float* ob = o + (int64_t)b * DV * N;
   float qB[RT][A::KS], doB[RT][A::VS], L2[RT], dl[RT];
   constexpr int NA = RT == 4 ? 1 : 2;
   f32x4 dq[RT][NA];
@@ -295,7 +284,12 @@ __global__ void __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(AttnOcc
 #pragma unroll
     for (int u = 0; u < A::VS; ++u) doB[q][u] = ld1<false>(gob, 4 * u + g, DV, N, n, N);      // dO^T[dv 4u+g][query c]
     L2[q] = n < N ? lse[(int64_t)b * N + n] * LOG2E : INFINITY;                               // dead query: p = 0
-    dl[q] = n < N ? delta[(int64_t)b * N + n] : 0.f;
+    // delta[n] = sum_v go[v][n] o[v][n]: this lane's dv rows, then the four lane groups of the query (no launch of its own)
+    float dsum = 0.f;
+#pragma unroll
+    for (int u = 0; u < A::VS; ++u) dsum = fmaf(doB[q][u], ld1<false>(ob, 4 * u + g, DV, N, n, N), dsum);
+    dl[q] = group_sum(dsum);
+    if (g == 0 && n < N) delta[(int64_t)b * N + n] = dl[q];
 #pragma unroll
     for (int a = 0; a < NA; ++a) dq[q][a] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -417,12 +411,16 @@ __global__ void __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(AttnOcc
   }
 }
 
-// out[i] = sum_s part[s][i]  (fixed order)
-__global__ void __launch_bounds__(AT) attn_reduce_k_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int QS) {
-  for (int64_t i = blockIdx.x * (int64_t)AT + threadIdx.x; i < n; i += gridDim.x * (int64_t)AT) {
+// out[i] = sum_s part[s][i]  (fixed order), for the two partial buffers of a backward pass (d phi, d g) in one launch
+__global__ void __launch_bounds__(AT) attn_reduce_k_kernel(const float* __restrict__ part1, float* __restrict__ out1, int64_t n1,
+                                                           const float* __restrict__ part2, float* __restrict__ out2, int64_t n2, int QS) {
+  for (int64_t i = blockIdx.x * (int64_t)AT + threadIdx.x; i < n1 + n2; i += gridDim.x * (int64_t)AT) {
+    const bool first = i < n1;
+    const float* part = first ? part1 : part2;
+    const int64_t n = first ? n1 : n2, e = first ? i : i - n1;
     float acc = 0.f;
-    for (int sidx = 0; sidx < QS; ++sidx) acc += part[sidx * n + i];
-    out[i] = acc;
+    for (int sidx = 0; sidx < QS; ++sidx) acc += part[sidx * n + e];
+    (first ? out1 : out2)[e] = acc;
   }
 }
 
@@ -461,16 +459,14 @@ int launch_bwd(const float* go, const float* theta, const float* phi, const floa
   float* delta = ws;
   float* pphi = ws + (((int64_t)B * N + 3) / 4) * 4;
   float* pg = pphi + (int64_t)QS * B * D * M;
-  dim3 gd((N + AT - 1) / AT, B);
   const int vecM = vec_rows(g, M) && vec_rows(phi, M);
   const int vecN = vec_rows(theta, N) && vec_rows(go, N) && vec_rows(lse, N) && vec_rows(delta, N);
-  attn_delta_kernel<<<gd, AT, 0, st>>>(go, o, delta, DV, N);
   if (attn_rt(B, N) == 4) {
     dim3 gq((N + 255) / 256, B);
-    attn_bwd_q_kernel<D, DV, 4><<<gq, AT, 0, st>>>(go, theta, phi, g, lse, delta, dtheta, N, M, vecM);
+    attn_bwd_q_kernel<D, DV, 4><<<gq, AT, 0, st>>>(go, theta, phi, g, o, lse, delta, dtheta, N, M, vecM);
   } else {
     dim3 gq((N + 63) / 64, B);
-    attn_bwd_q_kernel<D, DV, 1><<<gq, AT, 0, st>>>(go, theta, phi, g, lse, delta, dtheta, N, M, vecM);
+    attn_bwd_q_kernel<D, DV, 1><<<gq, AT, 0, st>>>(go, theta, phi, g, o, lse, delta, dtheta, N, M, vecM);
   }
   float* ophi = QS == 1 ? dphi : pphi;
   float* og = QS == 1 ? dg : pg;
@@ -483,8 +479,7 @@ int launch_bwd(const float* go, const float* theta, const float* phi, const floa
   }
   if (QS > 1) {
     const int64_t n1 = (int64_t)B * D * M, n2 = (int64_t)B * DV * M;
-    attn_reduce_k_kernel<<<tg_ew_grid(n1, AT), AT, 0, st>>>(pphi, dphi, n1, QS);
-    attn_reduce_k_kernel<<<tg_ew_grid(n2, AT), AT, 0, st>>>(pg, dg, n2, QS);
+    attn_reduce_k_kernel<<<tg_ew_grid(n1 + n2, AT), AT, 0, st>>>(pphi, dphi, n1, pg, dg, n2, QS);
   }
   return tg_launch_status();
 }
@@ -653,8 +648,7 @@ int launch_dbwd(const float* go, const float* theta, const float* phi, const flo
   float* pg = ws + (int64_t)S * B * D * M;
   attn_dbwd_kernel<D, DV, CPL><<<dim3(S, B), 64, 0, st>>>(go, theta, phi, g, lse, a, b, c, d_go, d_theta, pphi, pg, N, M, B);
   const int64_t n1 = (int64_t)B * D * M, n2 = (int64_t)B * DV * M;
-  attn_reduce_k_kernel<<<tg_ew_grid(n1, AT), AT, 0, st>>>(pphi, d_phi, n1, S);
-  attn_reduce_k_kernel<<<tg_ew_grid(n2, AT), AT, 0, st>>>(pg, d_g, n2, S);
+  attn_reduce_k_kernel<<<tg_ew_grid(n1 + n2, AT), AT, 0, st>>>(pphi, d_phi, n1, pg, d_g, n2, S);
   return tg_launch_status();
 }
 template <int D, int DV>

@@ -2313,6 +2313,44 @@ conv_upfwd_dma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
   }
 }
 
+// Bias gradient of the stride-2 forms, taken from the operands the weight-gradient kernel stages anyway (no pass of its own):
+//   mode 0 (pooled conv, bias over the `lo` channels = gy): the sum of the A fragments -- every gy value of a tile passes
+//          through them exactly once; by the workgroups of hi-chunk 0;
+//   mode 1 (up-conv, bias over the `hi` channels = gy at the high resolution): the sum of the B fragments at the four inner taps
+//          (u, v in {1, 2}): hi pixel (2r-1+u, 2c-1+v) is met once over all low-resolution pixels (r, c); by the lo-tile-0 workgroups.
+// Per-workgroup partials [S][channels] (fixed order inside: lane groups, then the four waves), finished by the fold kernel.
+template <int NT>
+__device__ __forceinline__ void s2_bias_finish(float* red /*LDS, >= 4 * 16 floats, free*/, float bsum_a, const float (&bsum_b)[NT], int mode,
+                                               float* __restrict__ bias_part, int split, int Clo, int Chi, int co0, int ci0, int lane,
+                                               int wave) {
+  const int j = lane & 15, h = lane >> 4;
+  if (mode == 0) {
+    float v = bsum_a;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (h == 0) red[wave * 16 + j] = v;
+  } else {
+    const bool inner = ((j >> 2) == 1 || (j >> 2) == 2) && ((j & 3) == 1 || (j & 3) == 2);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float v = inner ? bsum_b[n] : 0.f;
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+      if (lane == 0) red[wave * 16 + n] = v;
+    }
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < 16) {
+    const float v = (red[c] + red[16 + c]) + (red[32 + c] + red[48 + c]);
+    if (mode == 0) {
+      if (co0 + c < Clo) bias_part[(int64_t)split * Clo + co0 + c] = v;
+    } else if (c < NT && ci0 + c < Chi) {
+      bias_part[(int64_t)split * Chi + ci0 + c] = v;
+    }
+  }
+}
+
 // The third member of the family: T[o][i][u][v] = sum_{b, r, c} lo[b][o][r][c] * hi[b][i][2r-1+u][2c-1+v], the product both
 // weight gradients reduce to (pooled conv: lo = gy, hi = x; up-conv: lo = a, hi = gy), 16 taps per low-resolution pixel and
 // channel pair instead of 36 for the 3x3 weight gradient on the (materialised) high-resolution pair.  Same scheme as
@@ -2321,7 +2359,8 @@ constexpr int S2_CKW = 4, S2_NT = S2_CKW * 16 / 16;   // (measured: 4 beats 8 an
 template <class G>
 __global__ void __launch_bounds__(CT_THREADS)
 conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo, float* __restrict__ part, Shape s /*Cin = hi channels,
-                     Cout = lo channels, H x W = lo plane*/, int ntiles, int S, int vec_hi, int vec_lo) {
+                     Cout = lo channels, H x W = lo plane*/, int ntiles, int S, int vec_hi, int vec_lo,
+                     float* __restrict__ bias_part /*nullable*/, int bias_mode) {
   using P = Patch2x<G>;
   constexpr int CKW = S2_CKW, NT = S2_NT, CT = 16;
   constexpr int PATCH = CKW * P::CIS, GYT = CT * WG_GYS;
@@ -2340,8 +2379,9 @@ conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo,
   const int lane_b = P::pix(wave * 64) + 2 * h;                     // the wave's first pixel (its 64 pixels share an image)
   const int lane_a = j * WG_GYS + wave * 64 + h;
   f32x4 acc[NT];
+  float bsum_a = 0.f, bsum_b[NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < NT; ++n) { acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum_b[n] = 0.f; }
   PatchStager2x<G, CKW> ps;
   GyStager<G, CT> gs;
   const int H2 = 2 * s.H, W2 = 2 * s.W;
@@ -2365,8 +2405,14 @@ conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo,
       const int pg = 4 * g;
       const int goff = 2 * (pg / G::TW) * P::PWS + 2 * (pg % G::TW);
       const float a = gl[lane_a + 4 * g];
+      float b[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[colbase[n] + lane_b + goff], acc[n], 0, 0, 0);
+      for (int n = 0; n < NT; ++n) b[n] = pl[colbase[n] + lane_b + goff];
+      bsum_a += a;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bsum_b[n] += b[n];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[n], 0, 0, 0);
     }
   }
   __syncthreads();
@@ -2384,6 +2430,10 @@ conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo,
     const int co = co0 + (l >> 4) * 4 + r, ci = ci0 + n, tap = l & 15;
     if (co < s.Cout && ci < s.Cin) part[(((int64_t)split * s.Cout + co) * s.Cin + ci) * 16 + tap] = v;
   }
+  if (bias_part != nullptr && (bias_mode == 0 ? blockIdx.z == 0 : blockIdx.y == 0)) {      // (block-uniform)
+    __syncthreads();                                        // the partial sums above have been read out of `red`
+    s2_bias_finish<NT>(red, bsum_a, bsum_b, bias_mode, bias_part, split, s.Cout, s.Cin, co0, ci0, lane, wave);
+  }
 }
 
 // ---- conv_wgrad_s2_kernel with LDS-DMA staging (single buffer, as conv_wgrad_dma_kernel): same split, accumulation
@@ -2391,7 +2441,8 @@ conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo,
 template <class G>
 __global__ void __launch_bounds__(CT_THREADS)
 conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__ lo, float* __restrict__ part, Shape s /*Cin = hi
-                         channels, Cout = lo channels, H x W = lo plane*/, int ntiles, int S) {
+                         channels, Cout = lo channels, H x W = lo plane*/, int ntiles, int S, float* __restrict__ bias_part /*nullable*/,
+                         int bias_mode) {
   static_assert(G::NPIX == 256, "256-pixel tiles");
   using P = DPatch2x<G>;
   constexpr int CKW = S2_CKW, NT = S2_NT, CT = 16;
@@ -2414,8 +2465,9 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
   const int lane_b = P::pix(wave * 64) + 2 * h;
   const int lane_a = j * WG_GYS + wave * 64 + h;
   f32x4 acc[NT];
+  float bsum_a = 0.f, bsum_b[NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < NT; ++n) { acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum_b[n] = 0.f; }
   const int cvalid = min(CKW, s.Cin - ci0);
   for (int t = split; t < ntiles; t += S) {
     const TileCoord tc = decode_tile<G>(t, s.H, s.W);
@@ -2458,8 +2510,14 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
       const int pg = 4 * g;
       const int goff = 2 * (pg / G::TW) * P::PWS + 2 * (pg % G::TW);
       const float a = gl[lane_a + 4 * g];
+      float b[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pl[colbase[n] + lane_b + goff], acc[n], 0, 0, 0);
+      for (int n = 0; n < NT; ++n) b[n] = pl[colbase[n] + lane_b + goff];
+      bsum_a += a;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bsum_b[n] += b[n];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[n], 0, 0, 0);
     }
     if (s.prio) __builtin_amdgcn_s_setprio(3);
   }
@@ -2478,6 +2536,10 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
     const int co = co0 + (l >> 4) * 4 + r, ci = ci0 + n, tap = l & 15;
     if (co < s.Cout && ci < s.Cin) part[(((int64_t)split * s.Cout + co) * s.Cin + ci) * 16 + tap] = v;
   }
+  if (bias_part != nullptr && (bias_mode == 0 ? blockIdx.z == 0 : blockIdx.y == 0)) {      // (block-uniform)
+    __syncthreads();                                        // the partial sums above have been read out of `red`
+    s2_bias_finish<NT>(red, bsum_a, bsum_b, bias_mode, bias_part, split, s.Cout, s.Cin, co0, ci0, lane, wave);
+  }
 }
 
 // Sum of the S partials of T (fixed order) and fold onto the 3x3 taps, in one kernel: a workgroup owns 4 (lo, hi)
@@ -2485,7 +2547,20 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
 //   mode 0 (pooled conv, T[co][ci]):  gw[kh][kw] (+)= 0.25 sum_{dy,dx} T[dy+kh][dx+kw];
 //   mode 1 (up-conv, T[ci][co]):      gw[kh][kw] (+)= sum_{u: kh in S(u)} sum_{v: kw in S(v)} T[u][v], S = {2},{1,2},{0,1},{0}.
 __global__ void __launch_bounds__(256) s2wgrad_reduce_fold_kernel(const float* __restrict__ part, float* __restrict__ gw, int S, int Clo,
-                                                                  int Chi, int Cout, int Cin, int mode, int accumulate) {
+                                                                  int Chi, int Cout, int Cin, int mode, int accumulate,
+                                                                  const float* __restrict__ bias_part /*nullable: [S][Cout]*/,
+                                                                  float* __restrict__ gbias, int pair_blocks) {
+  if ((int)blockIdx.x >= pair_blocks) {
+    // the bias gradient: one wave per channel, lanes stride over the S partials, fixed-order wavefront sum
+    const int c = ((int)blockIdx.x - pair_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= Cout) return;                        // (whole wave)
+    float v = 0.f;
+    for (int sidx = lane; sidx < S; sidx += 64) v += bias_part[(int64_t)sidx * Cout + c];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (lane == 0) gbias[c] = accumulate ? gbias[c] + v : v;
+    return;
+  }
   __shared__ float red[4][4][16];                 // [slice][pair][tap]
   __shared__ float T[4][16];
   const int tap = threadIdx.x & 15, pr = (threadIdx.x >> 4) & 3, sl = threadIdx.x >> 6;
@@ -3006,14 +3081,14 @@ static inline int s2_splits(int tiles, int lo_tiles, int hi_chunks) {
   if (S > tiles) S = tiles;
   return S;
 }
-// workspace: S partials of T
+// workspace: S partials of T, then S partials of the bias gradient (over the wider of the two channel counts)
 static size_t s2_workspace(int B, int Clo, int Chi, int H, int W) {
   const GeoId g = pick_geo(H, W);
   const int S = s2_splits(geo_tiles(g, B, H, W), (Clo + 15) / 16, (Chi + S2_CKW - 1) / S2_CKW);
-  return (size_t)S * Clo * Chi * 16 * sizeof(float);
+  return ((size_t)S * Clo * Chi * 16 + (size_t)S * (Clo > Chi ? Clo : Chi)) * sizeof(float);
 }
-static int s2_wgrad(const float* hi, const float* lo, float* gw, float* ws, size_t ws_bytes, int B, int Clo, int Chi, int H, int W,
-                    int Cout, int Cin, int mode, int accumulate, hipStream_t st) {
+static int s2_wgrad(const float* hi, const float* lo, float* gw, float* gbias, float* ws, size_t ws_bytes, int B, int Clo, int Chi, int H,
+                    int W, int Cout, int Cin, int mode, int accumulate, hipStream_t st) {
   const GeoId g = pick_geo(H, W);
   if (!s2_geo(g) || check_shape(B, Clo, Chi, 2 * H, 2 * W, 3) != TG_OK) return TG_EUNSUPPORTED;
   if (ws_bytes < s2_workspace(B, Clo, Chi, H, W)) return TG_EWORKSPACE;
@@ -3021,14 +3096,17 @@ static int s2_wgrad(const float* hi, const float* lo, float* gw, float* ws, size
   const int S = s2_splits(tiles, lo_tiles, hi_chunks);
   Shape s{B, Chi, Clo, H, W};
   dim3 grid(S, lo_tiles, hi_chunks);
+  float* bias_part = gbias ? ws + (size_t)S * Clo * Chi * 16 : nullptr;      // [S][Cout]: Cout == Clo (mode 0) or Chi (mode 1)
   const int vh = plane_vec_ok(hi, 2 * W), vl = plane_vec_ok(lo, W);
   if (vh && vl && dma_knobs().enable && dma_knobs().wgrad && (int64_t)B * (Chi > Clo ? Chi : Clo) * H * W * 16 < (1ll << 31)) {
     s.prio = dma_knobs().prio;
-    TG_S2_DISPATCH(g, conv_wgrad_s2_dma_kernel, hi, lo, ws, s, tiles, S);
+    TG_S2_DISPATCH(g, conv_wgrad_s2_dma_kernel, hi, lo, ws, s, tiles, S, bias_part, mode);
   } else {
-    TG_S2_DISPATCH(g, conv_wgrad_s2_kernel, hi, lo, ws, s, tiles, S, vh, vl);
+    TG_S2_DISPATCH(g, conv_wgrad_s2_kernel, hi, lo, ws, s, tiles, S, vh, vl, bias_part, mode);
   }
-  s2wgrad_reduce_fold_kernel<<<(Clo * Chi + 3) / 4, 256, 0, st>>>(ws, gw, S, Clo, Chi, Cout, Cin, mode, accumulate);
+  const int pair_blocks = (Clo * Chi + 3) / 4;
+  s2wgrad_reduce_fold_kernel<<<pair_blocks + (gbias ? (Cout + 3) / 4 : 0), 256, 0, st>>>(ws, gw, S, Clo, Chi, Cout, Cin, mode, accumulate,
+                                                                                       bias_part, gbias, pair_blocks);
   return tg_launch_status();
 }
 
@@ -3037,18 +3115,18 @@ size_t tg_poolconv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W) {
   return s2_workspace(B, Cout, Cin, H, W);
 }
 int tg_poolconv3x3_wgrad(const float* x, const float* gy, float* gw, float* workspace, size_t workspace_bytes, int B, int Cin,
-                         int Cout, int H, int W, int accumulate, void* stream) {
+                         int Cout, int H, int W, int accumulate, float* gbias, void* stream) {
   TG_CHECK_PTR(x); TG_CHECK_PTR(gy); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
-  return s2_wgrad(x, gy, gw, workspace, workspace_bytes, B, Cout, Cin, H, W, Cout, Cin, 0, accumulate, tg_stream(stream));
+  return s2_wgrad(x, gy, gw, gbias, workspace, workspace_bytes, B, Cout, Cin, H, W, Cout, Cin, 0, accumulate, tg_stream(stream));
 }
 size_t tg_upconv3x3_wgrad_workspace(int B, int Cin, int Cout, int H, int W) {
   if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
   return s2_workspace(B, Cin, Cout, H, W);
 }
 int tg_upconv3x3_wgrad(const float* a, const float* gy, float* gw, float* workspace, size_t workspace_bytes, int B, int Cin,
-                       int Cout, int H, int W, int accumulate, void* stream) {
+                       int Cout, int H, int W, int accumulate, float* gbias, void* stream) {
   TG_CHECK_PTR(a); TG_CHECK_PTR(gy); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
-  return s2_wgrad(gy, a, gw, workspace, workspace_bytes, B, Cin, Cout, H, W, Cout, Cin, 1, accumulate, tg_stream(stream));
+  return s2_wgrad(gy, a, gw, gbias, workspace, workspace_bytes, B, Cin, Cout, H, W, Cout, Cin, 1, accumulate, tg_stream(stream));
 }
 
 int tg_poolconv3x3_weights(const float* w, float* w4, float* wp, int Cout, int Cin, void* stream) {

@@ -865,14 +865,18 @@ class _UpConv3x3(Function):
             B, Cin, H, W = a.shape
             Cout = w.shape[0]
             if K().upconv3x3_dgrad_supported(B, Cin, Cout, H, W):
-                # 16-tap stride-2 weight gradient on (a, gy): no up2x(a), 2.25x fewer FLOPs
+                # 16-tap stride-2 weight gradient on (a, gy): no up2x(a), 2.25x fewer FLOPs; the bias gradient rides along
+                # (the kernel sums the gy values it stages) when both go the same way (both sinks, or both returned)
                 ws = _ws(a, K().upconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
+                with_b = need_b and ((sink_w is None) == (sink_b is None))
                 if sink_w is None:
                     gw = torch.empty_like(w)
-                    K().upconv3x3_wgrad(a, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0)
+                    gb = torch.empty_like(bias) if with_b else None
+                    K().upconv3x3_wgrad(a, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, gb)
                 else:
                     with _beside_backward(a, gy, ws):
-                        K().upconv3x3_wgrad(a, gy, sink_w, ws, ws.numel() * 4, B, Cin, Cout, H, W, 1)
+                        K().upconv3x3_wgrad(a, gy, sink_w, ws, ws.numel() * 4, B, Cin, Cout, H, W, 1, sink_b if with_b else None)
+                need_b = need_b and not with_b
             elif sink_w is not None:
                 _conv_wgrad_into(upsample_nearest2x(a), gy, sink_w, None, 3, accumulate=1)
             else:
@@ -987,12 +991,18 @@ class _PoolConv(Function):
                 Cout = w.shape[0]
                 sink_w = _grad_sink(w)
                 ws = _ws(x, K().poolconv3x3_wgrad_workspace(B, Cin, Cout, H2 // 2, W2 // 2))
+                # the bias gradient (at the LOW resolution) rides along: the kernel sums the gy values it stages
+                sink_b = _grad_sink(bias) if need_b else None
+                with_b = need_b and ((sink_w is None) == (sink_b is None))
                 if sink_w is None:
                     gw = torch.empty_like(w)
-                    K().poolconv3x3_wgrad(x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H2 // 2, W2 // 2, 0)
+                    gb = torch.empty_like(bias) if with_b else None
+                    K().poolconv3x3_wgrad(x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H2 // 2, W2 // 2, 0, gb)
                 else:
                     with _beside_backward(x, gy, ws):
-                        K().poolconv3x3_wgrad(x, gy, sink_w, ws, ws.numel() * 4, B, Cin, Cout, H2 // 2, W2 // 2, 1)
+                        K().poolconv3x3_wgrad(x, gy, sink_w, ws, ws.numel() * 4, B, Cin, Cout, H2 // 2, W2 // 2, 1,
+                                              sink_b if with_b else None)
+                need_b = need_b and not with_b
         if need_b:                                                   # bias gradient at the LOW resolution
             sink_b = _grad_sink(bias)
             if sink_b is not None:
@@ -1035,10 +1045,10 @@ class _PoolConvT(Function):
                 ws = _ws(v, K().poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
                 if sink is None:
                     a_w = torch.empty_like(w)
-                    K().poolconv3x3_wgrad(v, gy, a_w, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0)
+                    K().poolconv3x3_wgrad(v, gy, a_w, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, None)
                 else:
                     with _beside_backward(v, gy, ws):
-                        K().poolconv3x3_wgrad(v, gy, sink, ws, ws.numel() * 4, B, Cin, Cout, H, W, 1)
+                        K().poolconv3x3_wgrad(v, gy, sink, ws, ws.numel() * 4, B, Cin, Cout, H, W, 1, None)
         return a_gy, a_w
 
 

@@ -37,6 +37,7 @@ class RngFeed:
         self.key = None         # batch shape the plan was recorded for
         self._spec = None       # (generator state before, after) a speculative draw of the next step's inputs
         self._uploaded = None   # event behind the last host -> device copies of the staging buffers
+        self._arena = self._host_arena = None   # one allocation behind all of an adopted plan's buffers
 
     def _draw_cpu(self, kind, rows, cols):
         if kind == 'z':
@@ -67,15 +68,26 @@ class RngFeed:
 
     def adopt(self, plan):
         """Start from a plan that is known in advance (the stock trainers' own draw order) instead of recording it during a
-        first inline-drawing step: every step, the first included, then has the same structure."""
-        self.plan, self.static, self.host = [], [], []
-        for kind, rows, cols in plan:
+        first inline-drawing step: every step, the first included, then has the same structure.
+
+        All of the plan's buffers are slices of ONE device arena (and one pinned staging arena): a step uploads its random
+        inputs with a single copy, and the latents lie back to back -- whatever else is drawn between them -- so that the two
+        generator passes of a step run over them as one (2B, latent) tensor without joining them first (functional._join)."""
+        self.plan = [tuple(p) for p in plan]
+        sizes = [rows * (cols if kind == 'z' else 1) for kind, rows, cols in self.plan]
+        order = sorted(range(len(self.plan)), key=lambda i: (self.plan[i][0] != 'z', i))
+        offsets, total = {}, 0
+        for i in order:
+            offsets[i] = total
+            total += (sizes[i] + 3) // 4 * 4                      # 16-byte aligned slices
+        self._arena = torch.zeros(max(total, 1), dtype=torch.float32, device=self.device)
+        host = torch.zeros(max(total, 1), dtype=torch.float32)
+        self._host_arena = host.pin_memory() if self._arena.is_cuda else host
+        self.static, self.host = [], []
+        for i, (kind, rows, cols) in enumerate(self.plan):
             width = cols if kind == 'z' else 1
-            buf = torch.empty(rows, width, dtype=torch.float32, device=self.device)
-            host = torch.empty(rows, width, dtype=torch.float32)
-            self.plan.append((kind, rows, cols))
-            self.static.append(buf)
-            self.host.append(host.pin_memory() if buf.is_cuda else host)
+            self.static.append(self._arena[offsets[i]:offsets[i] + sizes[i]].view(rows, width))
+            self.host.append(self._host_arena[offsets[i]:offsets[i] + sizes[i]].view(rows, width))
         self.cursor = 0
 
     def _draw_into_host(self):
@@ -115,8 +127,11 @@ class RngFeed:
             if self._uploaded is not None:
                 self._uploaded.synchronize()
             self._draw_into_host()
-        for buf, host in zip(self.static, self.host):
-            buf.copy_(host, non_blocking=True)
+        if self._arena is not None:
+            self._arena.copy_(self._host_arena, non_blocking=True)       # the whole plan in one upload
+        else:
+            for buf, host in zip(self.static, self.host):
+                buf.copy_(host, non_blocking=True)
         if self.static and self.static[0].is_cuda:
             self._uploaded = torch.cuda.Event()
             self._uploaded.record()

@@ -107,19 +107,25 @@ class Emulator:
     def poolconv3x3_wgrad_workspace(self, B, Cin, Cout, H, W):
         return 16
 
-    def poolconv3x3_wgrad(self, x, gy, gw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate):
+    def poolconv3x3_wgrad(self, x, gy, gw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, gbias=None):
         g_hi = (_v(gy, B, Cout, H, W) * 0.25).repeat_interleave(2, 2).repeat_interleave(2, 3)
         r = torch.nn.grad.conv2d_weight(_v(x, B, Cin, 2 * H, 2 * W), (Cout, Cin, 3, 3), g_hi, padding=1)
         gw.copy_(gw + r if accumulate else r)
+        if gbias is not None:
+            rb = _v(gy, B, Cout, H, W).sum((0, 2, 3))
+            gbias.copy_(gbias + rb if accumulate else rb)
         return 0
 
     def upconv3x3_wgrad_workspace(self, B, Cin, Cout, H, W):
         return 16
 
-    def upconv3x3_wgrad(self, a, gy, gw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate):
+    def upconv3x3_wgrad(self, a, gy, gw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, gbias=None):
         a_hi = _v(a, B, Cin, H, W).repeat_interleave(2, 2).repeat_interleave(2, 3)
         r = torch.nn.grad.conv2d_weight(a_hi, (Cout, Cin, 3, 3), _v(gy, B, Cout, 2 * H, 2 * W), padding=1)
         gw.copy_(gw + r if accumulate else r)
+        if gbias is not None:
+            rb = _v(gy, B, Cout, 2 * H, 2 * W).sum((0, 2, 3))
+            gbias.copy_(gbias + rb if accumulate else rb)
         return 0
 
     # theta | phi | g of SelfAttention2d as one pass: the three 1x1 convolutions, their joint input gradient, their filter gradients

@@ -106,16 +106,17 @@ def test_sync_bn_two_ranks_equal_single_process_full_batch(kind):
         assert abs(got - want[name]) <= 1e-4 * max(abs(want[name]), 1e-6), (name, got, want[name])
 
 
-@pytest.mark.parametrize('case,world', [('c128a3_cnn_b64', 2), ('c128a3_iqn_b64', 2), ('c128a3_cnn_b256', 4)])
+@pytest.mark.parametrize('case,world', [('c128a3_cnn_b64', 2), ('c128a3_iqn_b64', 2), ('c128a3_cnn_b256', 4), ('c128a3_iqn_b512', 4)])
 def test_sync_bn_ranks_reproduce_the_reference_fixture_at_the_global_batch(case, world):
     """BASELINE.json configs 4 / 5 at the benched model: the REFERENCE's own step (128:3, fixtures written by its CNNTrainer /
     IQNTrainer) reproduced by several ranks with synchronised BatchNorm -- global z / tau streams sliced per rank, images
     sharded, gradients averaged.  Batch 64 as two ranks of 32, and **config 4 at its real global batch: 256 images as four
-    ranks of 64** (the per-GPU batch of the bench; on hardware it is eight ranks of 32).  1e-4 on the three losses (g_loss of the
+    ranks of 64** (the per-GPU batch of the bench; on hardware it is eight ranks of 32), and **config 5 (IQN) at its global batch
+    of 512 as four ranks of 128** (on hardware eight ranks of 64).  1e-4 on the three losses (g_loss of the
     batch-256 fixture: its measured knife-edge bound), like one GPU."""
     from conftest import load_golden
     fx = load_golden(case)
-    assert fx['batch'] in (64, 256) and fx.get('flags', {}) == {}
+    assert fx['batch'] in (64, 256, 512) and fx.get('flags', {}) == {}
     # _build loads procedural weights with seeds 7/8/9 = the fixtures' weight_seed, +1, +2
     assert fx['weight_seed'] == 7 and fx['rng_seed'] == 1234
     res = _run(fx['trainer'], 'sync_bn', 1, global_batch=fx['batch'], world=world, config=fx['config'], attention=fx['attention'],

@@ -579,3 +579,28 @@ def test_speculative_rng_prefetch_is_invisible():
         return out
 
     assert run(True) == run(False)
+
+
+def test_adopted_rng_plan_lives_in_one_arena_with_the_latents_back_to_back():
+    """RngFeed.adopt: one device arena behind the whole plan (a single upload per step), the latents adjacent whatever is
+    drawn between them (the shared generator pass joins them without a copy), and the values still the reference's stream in
+    draw order (trainer.py:153-156, iqn.py:105-108)."""
+    from tartangan_amd.trainers.trainer import RngFeed
+    feed = RngFeed('cpu')
+    plan = [('z', 6, 8), ('tau', 6 * 3, 3), ('tau', 6 * 3, 3), ('z', 6, 8), ('tau', 6 * 3, 3)]
+    feed.adopt(plan)
+    z_d, z_g = feed.static[0], feed.static[3]
+    joined = TF._join(z_d, z_g)
+    assert joined.data_ptr() == z_d.data_ptr() and joined.shape == (12, 8)
+    assert all(t.untyped_storage().data_ptr() == feed._arena.untyped_storage().data_ptr() for t in feed.static)
+    assert all(t.data_ptr() % 16 == 0 for t in feed.static)
+    torch.manual_seed(11)
+    feed.refill()
+    torch.manual_seed(11)
+    for (kind, rows, cols), got in zip(plan, feed.static):
+        want = torch.randn(rows, cols) if kind == 'z' else torch.rand(rows, 1)
+        assert torch.equal(got, want)
+    # slices do not overlap: writing one leaves the others alone
+    before = [t.clone() for t in feed.static]
+    feed.static[1].fill_(7.)
+    assert all(torch.equal(a, b) for k, (a, b) in enumerate(zip(before, feed.static)) if k != 1)

@@ -140,7 +140,8 @@ def test_stride2_step_shapes_full_batch_after_lds_poison(K, shape):
         run_both(K, 'upconv3x3_dgrad', [gyh, w4t, torch.zeros(B, Cin, H, W), B, Cin, Cout, H, W], [2], tol=5e-5)
         ws = workspace(K.upconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
         poison_lds(K)
-        run_both(K, 'upconv3x3_wgrad', [a, gyh, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0], [2], tol=1e-4, scratch=[3])
+        run_both(K, 'upconv3x3_wgrad', [a, gyh, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, torch.zeros(Cout)], [2, 11],
+                 tol=1e-4, scratch=[3])
     x, gy = rnd(B, Cin, 2 * H, 2 * W, seed=5), rnd(B, Cout, H, W, seed=6)
     w4, wpp = torch.zeros(Cout, Cin, 4, 4), torch.zeros(4, Cin, Cout, 2, 2)
     E.poolconv3x3_weights(w, w4, wpp, Cout, Cin)
@@ -151,7 +152,8 @@ def test_stride2_step_shapes_full_batch_after_lds_poison(K, shape):
         run_both(K, 'poolconv3x3_dgrad', [gy, wpp, torch.zeros(B, Cin, 2 * H, 2 * W), B, Cin, Cout, H, W], [2], tol=5e-5)
         ws = workspace(K.poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
         poison_lds(K)
-        run_both(K, 'poolconv3x3_wgrad', [x, gy, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0], [2], tol=1e-4, scratch=[3])
+        run_both(K, 'poolconv3x3_wgrad', [x, gy, torch.zeros(Cout, Cin, 3, 3), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, torch.zeros(Cout)], [2, 11],
+                 tol=1e-4, scratch=[3])
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 16, 64, 64), (3, 32, 16, 32, 32), (2, 64, 32, 16, 16), (5, 128, 128, 8, 8), (20, 128, 128, 4, 4),
@@ -253,13 +255,16 @@ def test_stride2_weight_gradients(K, shape):
     # pooled conv: x high resolution (Cin), gy low resolution (Cout)
     x, gy = rnd(B, Cin, 2 * H, 2 * W), rnd(B, Cout, H, W, seed=3)
     ws = workspace(K.poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
-    for acc in (0, 1):
-        run_both(K, 'poolconv3x3_wgrad', [x, gy, w0.clone(), ws, ws.numel() * 4, B, Cin, Cout, H, W, acc], [2], tol=1e-4, scratch=[3])
+    b0 = rnd(Cout, seed=10)
+    for acc in (0, 1):       # with the bias gradient riding along (sum of gy), and without
+        run_both(K, 'poolconv3x3_wgrad', [x, gy, w0.clone(), ws, ws.numel() * 4, B, Cin, Cout, H, W, acc, b0.clone()], [2, 11], tol=1e-4, scratch=[3])
+    run_both(K, 'poolconv3x3_wgrad', [x, gy, w0.clone(), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, None], [2], tol=1e-4, scratch=[3])
     # up-conv: a low resolution (Cin), gy high resolution (Cout)
     a, gyh = rnd(B, Cin, H, W, seed=4), rnd(B, Cout, 2 * H, 2 * W, seed=5)
     ws = workspace(K.upconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
     for acc in (0, 1):
-        run_both(K, 'upconv3x3_wgrad', [a, gyh, w0.clone(), ws, ws.numel() * 4, B, Cin, Cout, H, W, acc], [2], tol=1e-4, scratch=[3])
+        run_both(K, 'upconv3x3_wgrad', [a, gyh, w0.clone(), ws, ws.numel() * 4, B, Cin, Cout, H, W, acc, b0.clone()], [2, 11], tol=1e-4, scratch=[3])
+    run_both(K, 'upconv3x3_wgrad', [a, gyh, w0.clone(), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, None], [2], tol=1e-4, scratch=[3])
 
 
 @pytest.mark.parametrize('op', ['pool_conv', 'up_conv'])

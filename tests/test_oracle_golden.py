@@ -16,7 +16,7 @@ import os
 # 128:3 at batch 32 / 64: 1-4 min each) are the same check and run with TG_SLOW_ORACLE=1 (done in the build container
 # whenever the oracle or a fixture changes); the GPU suite compares the HIP trainers with those fixtures directly.
 def _is_slow(c):
-    return c.endswith(('b64', 'b32', 'b256')) or c.startswith('c512') or c in ('c128big_cnn_b8', 'c256a3_cnn_b8')
+    return c.endswith(('b64', 'b32', 'b256', 'b512')) or c.startswith('c512') or c in ('c128big_cnn_b8', 'c256a3_cnn_b8')
 
 
 FAST = [c for c in golden_cases() if not _is_slow(c)]

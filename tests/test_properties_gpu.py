@@ -131,7 +131,7 @@ def test_stride2_convs_are_one_trilinear_form_at_full_size(K, step_shapes, form)
             K.upconv3x3_weights_t(w, w4t, Cout, Cin)
             K.upconv3x3_dgrad(g, w4t, gx, B, Cin, Cout, H, W)
             ws = torch.empty(K.upconv3x3_wgrad_workspace(B, Cin, Cout, H, W) // 4 + 4, device='cuda')
-            K.upconv3x3_wgrad(x, g, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0)
+            K.upconv3x3_wgrad(x, g, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, None)
             # and the form itself, on one image, against the textbook composition
             want = F.conv2d(F.interpolate(x[:1], scale_factor=2), w, None, padding=1)
         else:
@@ -142,7 +142,7 @@ def test_stride2_convs_are_one_trilinear_form_at_full_size(K, step_shapes, form)
             K.poolconv3x3_fwd(x, w4, None, None, y, B, Cin, Cout, H, W)
             K.poolconv3x3_dgrad(g, wp, gx, B, Cin, Cout, H, W)
             ws = torch.empty(K.poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W) // 4 + 4, device='cuda')
-            K.poolconv3x3_wgrad(x, g, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0)
+            K.poolconv3x3_wgrad(x, g, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, None)
             want = F.avg_pool2d(F.conv2d(x[:1], w, None, padding=1), 2)
         a, b, c = _dot(y, g), _dot(x, gx), _dot(w, gw)
         assert _same(a, b, 2e-5) and _same(a, c, 2e-5), (form, (B, Cin, Cout, H, W), a, b, c)

@@ -29,7 +29,7 @@ for (Cin, Cout, H) in [(16, 16, 64), (32, 32, 32), (64, 64, 16), (128, 128, 8)]:
     t1 = timeit(lambda: K.poolconv3x3_fwd(x, w4, bias, None, y, B, Cin, Cout, H, H))
     if only == 'fwd': continue
     t2 = timeit(lambda: K.poolconv3x3_dgrad(gy, wp, gx, B, Cin, Cout, H, H))
-    t3 = timeit(lambda: K.poolconv3x3_wgrad(x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, H, 0))
+    t3 = timeit(lambda: K.poolconv3x3_wgrad(x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, H, 0, None))
     tf = lambda t: fl / t / 1e6
     print(f'pool {Cin:3d}->{Cout:3d} out {H:3d}^2  {fl/1e9:5.2f} GF  fwd {t1:6.1f} us ({tf(t1):5.1f} TF)  dgrad {t2:6.1f} ({tf(t2):5.1f})  wgrad {t3:6.1f} ({tf(t3):5.1f})')
 for (Cin, Cout, H) in [(128, 128, 8), (128, 64, 16), (64, 32, 32), (32, 16, 64)]:       # up-conv: a (Cin, H) -> y (Cout, 2H)
