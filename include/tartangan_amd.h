@@ -62,6 +62,8 @@ int tg_upconv3x3_fwd(const float* a, const float* wp, const float* bias /*nullab
  * Only where the low-resolution plane gives >= 256 workgroups (tg_upconv3x3_dgrad_supported); callers fall back to
  * tg_conv2d_dgrad + tg_pool2 otherwise.                                                                    */
 int tg_upconv3x3_weights_t(const float* w, float* w4t, int Cout, int Cin, void* stream);
+/* both layouts in one launch (a training step needs both) */
+int tg_upconv3x3_weights_pair(const float* w, float* wp, float* w4t, int Cout, int Cin, void* stream);
 int tg_upconv3x3_dgrad_supported(int B, int Cin, int Cout, int H, int W);
 int tg_upconv3x3_dgrad(const float* gy, const float* w4t, float* ga, int B, int Cin, int Cout, int H, int W, void* stream);
 /* AvgPool2d(2)(conv3x3(x) + bias) [+ residual] as ONE 4x4-tap stride-2 convolution (discriminator.py:60-66: the second
@@ -134,6 +136,11 @@ typedef int64_t tg_host_i64;
 int tg_conv2d_wgrad_partials(const float* x, const float* gy, float* workspace, size_t workspace_bytes,
                              int B, int Cin, int Cout, int H, int W, int ks, int want_bias, void* stream);
 int tg_conv2d_wgrad_reduce_batch(const tg_host_i64* items /*host*/, int n_items, void* stream);
+/* tg_poolconv3x3_weights for n_items layers in one launch (a discriminator's stride-2 layers all need their derived filters at
+ * the start of a pass).  `items`: HOST array of n_items x TG_FORM_ITEM_FIELDS words: [0] w  [1] w4  [2] wp (device addresses)
+ * [3] Cout  [4] Cin.  Same arithmetic per layer as the single call. */
+#define TG_FORM_ITEM_FIELDS 5
+int tg_poolconv3x3_weights_batch(const tg_host_i64* items /*host*/, int n_items, void* stream);
 /* out[c] (+)= sum_{b,p} x[b][c][p]   (linear bias grad); workspace: tg_bn_workspace(B,C,HW) bytes */
 int tg_channel_sum(const float* x, float* out, float* workspace, int B, int C, int HW, int accumulate,
                    void* stream);

@@ -397,6 +397,46 @@ struct DbwdBody {
   }
 };
 
+// the same with the reduction finished inside the apply pass (big planes): arithmetic identical to dbwd_stage2 + DbwdBody
+struct DbwdSumsBody {
+  const float *v, *gz, *x; float *adj_gz, *adj_x;
+  const double* partial;
+  const float *mean, *invstd, *gamma, *beta, *vgamma, *vbeta;
+  float* adj_gamma;
+  float slope; int accumulate, B, HW, S;
+  DbwdBody::Ch h;
+  __device__ void begin(const Chan& ch, bool lead) {
+    const int c = ch.c;
+    const double n = (double)B * HW;
+    const double S1 = planes::gather(partial, c, S, 5, 0), S2 = planes::gather(partial, c, S, 5, 1);
+    const double S3 = planes::gather(partial, c, S, 5, 2), S4 = planes::gather(partial, c, S, 5, 3);
+    const double S5 = planes::gather(partial, c, S, 5, 4);
+    const double r = (double)invstd[c], g = (double)gamma[c];
+    const double vg = vgamma ? (double)vgamma[c] : 0.0;
+    const double A = S5 - S1 * S3 / n - S2 * S4 / n;
+    const double cg = S4 / n, cv = S2 / n;
+    const double qm = -g * r * (cg * S1 / n + cv * S3 / n) + vg * S3 / n;
+    const double qx = -g * r * (cg * S2 / n + cv * S4 / n) + vg * S4 / n;
+    h.r = invstd[c]; h.mu = mean[c]; h.a = gamma[c] * h.r; h.b = beta[c] - h.mu * h.a; h.gr = h.a;
+    h.vg = vgamma ? vgamma[c] : 0.f; h.vb = vbeta ? vbeta[c] : 0.f;
+    h.k0 = (float)(S1 / n); h.k1 = (float)(S2 / n); h.cg = (float)cg; h.cv = (float)cv;
+    h.qm = (float)qm; h.qx = (float)qx; h.k6 = (float)(g * A * r * r / n);
+    if (lead && threadIdx.x == 0) adj_gamma[c] = (float)(r * A) + (accumulate ? adj_gamma[c] : 0.f);
+  }
+  struct V { float4 w, g, q; };
+  __device__ V ld(int64_t off) const {
+    return V{*reinterpret_cast<const float4*>(v + off), *reinterpret_cast<const float4*>(gz + off), *reinterpret_cast<const float4*>(x + off)};
+  }
+  __device__ void st(const Chan&, int64_t off, const V& t) const {
+    const DbwdBody e{v, gz, x, adj_gz, adj_x, mean, invstd, gamma, beta, vgamma, vbeta, nullptr, slope};
+    float4 og, ox;
+    e.elem(h, t.w.x, t.g.x, t.q.x, og.x, ox.x); e.elem(h, t.w.y, t.g.y, t.q.y, og.y, ox.y);
+    e.elem(h, t.w.z, t.g.z, t.q.z, og.z, ox.z); e.elem(h, t.w.w, t.g.w, t.q.w, og.w, ox.w);
+    *reinterpret_cast<float4*>(adj_gz + off) = og;
+    *reinterpret_cast<float4*>(adj_x + off) = ox;
+  }
+};
+
 static inline int chan_grid(int C) { return (C + 63) / 64; }
 
 // ------------------------------------------------------------------ small tensors: one workgroup per channel
@@ -972,6 +1012,12 @@ int tg_bn_act_dbwd(const float* v, const float* vgamma, const float* vbeta, cons
   RedDbwd red{v, gz, x, mean, invstd, gamma, beta, slope, 0.f, 0.f, 0.f, 0.f};
   const bool al = tg_aligned16(x) && tg_aligned16(gz) && tg_aligned16(v) && tg_aligned16(adj_gz) && tg_aligned16(adj_x);
   planes::launch_reduce(red, p.partial, B, C, HW, st, al);
+  if (planes::big(HW) && al) {                     // the per-channel coefficients are finished inside the apply pass
+    DbwdSumsBody body{v, gz, x, adj_gz, adj_x, p.partial, mean, invstd, gamma, beta, vgamma, vbeta, adj_gamma, slope, accumulate, B, HW,
+                      planes::splits(B, C, HW), {}};
+    planes::launch_map_begin(body, B, C, HW, st);
+    return tg_launch_status();
+  }
   dbwd_stage2<<<C, 64, 0, st>>>(p.partial, gamma, invstd, vgamma, adj_gamma, p.coef, B, C, HW,
                                            planes::splits(B, C, HW), accumulate);
   DbwdBody body{v, gz, x, adj_gz, adj_x, mean, invstd, gamma, beta, vgamma, vbeta, p.coef, slope};

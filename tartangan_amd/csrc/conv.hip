@@ -1801,6 +1801,42 @@ __global__ void __launch_bounds__(256) upconvT_weights_kernel(const float* __res
   for (int u = 0; u < 4; ++u) { o[u * 4 + 0] = r[u][2]; o[u * 4 + 1] = r[u][1] + r[u][2]; o[u * 4 + 2] = r[u][0] + r[u][1]; o[u * 4 + 3] = r[u][0]; }
 }
 
+// Both derived layouts of an up-conv filter in one launch (a training step needs both: wp for the forward, w4t for the input
+// gradient): thread = (co, ci), the 3x3 filter read once.  Same arithmetic as the two kernels above.
+__global__ void __launch_bounds__(256) upconv_weights_pair_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ w4t,
+                                                                  int Cout, int Cin) {
+  const int e = blockIdx.x * 256 + threadIdx.x;          // e = co * Cin + ci
+  const int n = Cout * Cin;
+  if (e >= n) return;
+  const int co = e / Cin, ci = e - co * Cin;
+  float k[3][3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i / 3][i % 3] = w[(int64_t)e * 9 + i];
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      float r[2][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        r[0][c] = dy == 0 ? k[0][c] : k[0][c] + k[1][c];
+        r[1][c] = dy == 0 ? k[1][c] + k[2][c] : k[2][c];
+      }
+      float* o = wp + ((int64_t)(dy * 2 + dx) * n + e) * 4;
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty) {
+        o[ty * 2 + 0] = dx == 0 ? r[ty][0] : r[ty][0] + r[ty][1];
+        o[ty * 2 + 1] = dx == 0 ? r[ty][1] + r[ty][2] : r[ty][2];
+      }
+    }
+  float r[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { r[0][c] = k[2][c]; r[1][c] = k[1][c] + k[2][c]; r[2][c] = k[0][c] + k[1][c]; r[3][c] = k[0][c]; }
+  float* o = w4t + ((int64_t)ci * Cout + co) * 16;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { o[u * 4 + 0] = r[u][2]; o[u * 4 + 1] = r[u][1] + r[u][2]; o[u * 4 + 2] = r[u][0] + r[u][1]; o[u * 4 + 3] = r[u][0]; }
+}
+
 template <class G>
 struct Patch2x {                       // high-resolution windows of a low-resolution tile (one per image of the tile)
   static constexpr int PH = 2 * G::TH + 2, TW2 = 2 * G::TW;
@@ -2596,9 +2632,8 @@ __global__ void __launch_bounds__(256) s2wgrad_reduce_fold_kernel(const float* _
 // AvgPool2d(2) o conv3x3 = 0.25 * (transpose of the up-conv with the flipped, transposed filter): the same two kernels
 // with the roles swapped.  w4[co][ci][u][v] = 0.25 * sum_{kh in S'(u), kw in S'(v)} w[co][ci][kh][kw], S' = {0},{0,1},{1,2},{2};
 // its input gradient is the four-phase kernel with wp[dy][dx][ci][co][ty][tx], rows dy=0: {w2 | w1+w0}, dy=1: {w2+w1 | w0}, x 0.25.
-__global__ void __launch_bounds__(256) poolconv_weights_kernel(const float* __restrict__ w, float* __restrict__ w4, float* __restrict__ wp,
-                                                               int Cout, int Cin) {
-  const int e = blockIdx.x * 256 + threadIdx.x;          // e = co * Cin + ci
+__device__ __forceinline__ void poolconv_weights_one(const float* __restrict__ w, float* __restrict__ w4, float* __restrict__ wp, int Cout,
+                                                     int Cin, int e /*co * Cin + ci*/) {
   const int n = Cout * Cin;
   if (e >= n) return;
   const int co = e / Cin, ci = e - co * Cin;
@@ -2630,6 +2665,21 @@ __global__ void __launch_bounds__(256) poolconv_weights_kernel(const float* __re
         o[ty * 2 + 1] = dx == 0 ? r[ty][1] + r[ty][0] : r[ty][0];
       }
     }
+}
+__global__ void __launch_bounds__(256) poolconv_weights_kernel(const float* __restrict__ w, float* __restrict__ w4, float* __restrict__ wp,
+                                                               int Cout, int Cin) {
+  poolconv_weights_one(w, w4, wp, Cout, Cin, blockIdx.x * 256 + threadIdx.x);
+}
+// ... of several layers in one launch (a network's stride-2 layers all need theirs at the start of a pass)
+constexpr int FB_MAX_ITEMS = 16;
+struct FormItem { const float* w; float* w4; float* wp; int Cout, Cin; };
+struct FormBatch { FormItem item[FB_MAX_ITEMS]; int block_end[FB_MAX_ITEMS]; int n; };
+__global__ void __launch_bounds__(256) poolconv_weights_batch_kernel(FormBatch fb) {
+  int i = 0;
+  while (i + 1 < fb.n && (int)blockIdx.x >= fb.block_end[i]) ++i;            // (block-uniform)
+  const int first = i == 0 ? 0 : fb.block_end[i - 1];
+  const FormItem& it = fb.item[i];
+  poolconv_weights_one(it.w, it.w4, it.wp, it.Cout, it.Cin, ((int)blockIdx.x - first) * 256 + threadIdx.x);
 }
 
 // =========================================================================== host dispatch
@@ -3056,6 +3106,12 @@ int tg_upconv3x3_weights_t(const float* w, float* w4t, int Cout, int Cin, void* 
   return tg_launch_status();
 }
 
+int tg_upconv3x3_weights_pair(const float* w, float* wp, float* w4t, int Cout, int Cin, void* stream) {
+  TG_CHECK_PTR(w); TG_CHECK_PTR(wp); TG_CHECK_PTR(w4t); TG_CHECK_POS(Cout); TG_CHECK_POS(Cin);
+  upconv_weights_pair_kernel<<<(Cout * Cin + 255) / 256, 256, 0, tg_stream(stream)>>>(w, wp, w4t, Cout, Cin);
+  return tg_launch_status();
+}
+
 int tg_upconv3x3_dgrad_supported(int B, int Cin, int Cout, int H, int W) {
   const GeoId g = pick_geo(H, W);
   return s2_geo(g) && check_shape(B, Cin, Cout, 2 * H, 2 * W, 3) == TG_OK &&
@@ -3127,6 +3183,29 @@ int tg_upconv3x3_wgrad(const float* a, const float* gy, float* gw, float* worksp
                        int Cout, int H, int W, int accumulate, float* gbias, void* stream) {
   TG_CHECK_PTR(a); TG_CHECK_PTR(gy); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
   return s2_wgrad(gy, a, gw, gbias, workspace, workspace_bytes, B, Cin, Cout, H, W, Cout, Cin, 1, accumulate, tg_stream(stream));
+}
+
+int tg_poolconv3x3_weights_batch(const tg_host_i64* items, int n_items, void* stream) {
+  if (n_items < 0) return TG_EINVAL;
+  if (n_items == 0) return TG_OK;
+  TG_CHECK_PTR(items);
+  hipStream_t st = tg_stream(stream);
+  for (int base = 0; base < n_items; base += FB_MAX_ITEMS) {
+    FormBatch fb;
+    fb.n = n_items - base < FB_MAX_ITEMS ? n_items - base : FB_MAX_ITEMS;
+    int blocks = 0;
+    for (int i = 0; i < fb.n; ++i) {
+      const tg_host_i64* it = items + (size_t)(base + i) * TG_FORM_ITEM_FIELDS;
+      const int Cout = (int)it[3], Cin = (int)it[4];
+      if (it[0] == 0 || it[1] == 0 || it[2] == 0 || Cout <= 0 || Cin <= 0) return TG_EINVAL;
+      fb.item[i] = FormItem{reinterpret_cast<const float*>(it[0]), reinterpret_cast<float*>(it[1]), reinterpret_cast<float*>(it[2]), Cout, Cin};
+      blocks += (Cout * Cin + 255) / 256;
+      fb.block_end[i] = blocks;
+    }
+    for (int i = fb.n; i < FB_MAX_ITEMS; ++i) { fb.item[i] = fb.item[0]; fb.block_end[i] = blocks; }
+    poolconv_weights_batch_kernel<<<blocks, 256, 0, st>>>(fb);
+  }
+  return tg_launch_status();
 }
 
 int tg_poolconv3x3_weights(const float* w, float* w4, float* wp, int Cout, int Cin, void* stream) {

@@ -14,6 +14,7 @@ Linear ops come as transpose pairs (each is the other's backward):
   repeat_rows <-> sum_reps;  channel_sum <-> channel_bcast.
 """
 import contextlib
+import weakref
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -300,6 +301,11 @@ class _Paired(Function):
         if hasattr(F, 'pair_full'):
             fargs = F.pair_full(fargs)
         rec = _PairCtx()
+        need, sub_need, pos = ctx.needs_input_grad, [], 1            # (what F's forward may consult to prepare its backward)
+        for kind in layout:
+            sub_need.append((need[pos] or need[pos + 1]) if kind == 'b' else need[pos])
+            pos += 2 if kind == 'b' else 1
+        rec.needs_input_grad = tuple(sub_need)
         out = F.forward(rec, *fargs)
         outs = out if isinstance(out, tuple) else (out,)
         kinds = out_spec if out_spec != '*' else 'b' * len(outs)
@@ -823,7 +829,15 @@ class _UpConv3x3(Function):
         if w.shape[2:] != (3, 3):
             raise RuntimeError('upconv3x3 needs a 3x3 filter')
         wp = a.new_empty(4, Cout, Cin, 2, 2)
-        K().upconv3x3_weights(w, wp, Cout, Cin)
+        ctx.w4t = None
+        need = getattr(ctx, 'needs_input_grad', ())
+        if need and need[0] and K().upconv3x3_dgrad_supported(B, Cin, Cout, H, W):
+            # the backward's filter layout in the same launch (the filter cannot change between this pass and its backward
+            # without autograd's version check failing on the saved ``w``)
+            ctx.w4t = a.new_empty(Cin, Cout, 4, 4)
+            K().upconv3x3_weights_pair(w, wp, ctx.w4t, Cout, Cin)
+        else:
+            K().upconv3x3_weights(w, wp, Cout, Cin)
         if residual is not None:
             residual = residual.contiguous()
         y = a.new_empty(B, Cout, 2 * H, 2 * W)
@@ -852,8 +866,10 @@ class _UpConv3x3(Function):
             Cout = w.shape[0]
             if K().upconv3x3_dgrad_supported(B, Cin, Cout, H, W):
                 # one 4x4-tap stride-2 pass over gy instead of dgrad3x3 at the high resolution + a 2x2 sum
-                w4t = a.new_empty(Cin, Cout, 4, 4)
-                K().upconv3x3_weights_t(w, w4t, Cout, Cin)
+                w4t = getattr(ctx, 'w4t', None)
+                if w4t is None:
+                    w4t = a.new_empty(Cin, Cout, 4, 4)
+                    K().upconv3x3_weights_t(w, w4t, Cout, Cin)
                 ga = torch.empty_like(a)
                 K().upconv3x3_dgrad(gy, w4t, ga, B, Cin, Cout, H, W)
             else:
@@ -919,18 +935,53 @@ PAIR_SPECS[_UpConv3x3] = ('b--b', 'h--', 'b')
 class _FilterForms:
     """Derived filter layouts of the stride-2 forms, kept for the length of one ``filter_forms()`` scope."""
     cache = None
+    owner = None            # the module whose pass the innermost scope brackets (or None)
 
 
 @contextlib.contextmanager
-def filter_forms():
+def filter_forms(owner=None):
     """Scope in which the parameters do not change (one half of a training step: the discriminator is evaluated up to six
     times between two of its optimiser steps): the 4x4 / four-phase layouts derived from a 3x3 filter are computed once
-    per scope instead of once per use.  Nothing outlives the scope, so nothing can go stale."""
-    outer, _FilterForms.cache = _FilterForms.cache, {}
+    per scope instead of once per use.  Nothing outlives the scope, so nothing can go stale.
+
+    ``owner`` (a module): the filters this scope had to derive are remembered FOR the module, and the next scope opened for it
+    derives all of them up front in ONE launch (tg_poolconv3x3_weights_batch) instead of one launch per layer as they come."""
+    outer, outer_owner = _FilterForms.cache, _FilterForms.owner
+    _FilterForms.cache, _FilterForms.owner = {}, owner
     try:
+        if owner is not None:
+            _derive_known_forms(owner)
         yield
     finally:
-        _FilterForms.cache = outer
+        _FilterForms.cache, _FilterForms.owner = outer, outer_owner
+
+
+_KNOWN_FORMS = weakref.WeakKeyDictionary()       # module -> {id(weight): weakref(weight)}; beside the module, not in it (pickling)
+
+
+def _known_forms(owner):
+    return _KNOWN_FORMS.setdefault(owner, {})
+
+
+def _derive_known_forms(owner):
+    known = _known_forms(owner)
+    ws = []
+    for key, ref in list(known.items()):
+        w = ref()
+        if w is None or not w.is_contiguous():
+            del known[key]
+        else:
+            ws.append(w)
+    if len(ws) < 2:
+        return                                   # (a single layer: its own call is the same one launch)
+    rows = []
+    for w in ws:
+        Cout, Cin = w.shape[:2]
+        w4 = w.new_empty(Cout, Cin, 4, 4)
+        wp = w.new_empty(4, Cin, Cout, 2, 2)
+        rows.append([w.data_ptr(), w4.data_ptr(), wp.data_ptr(), Cout, Cin])
+        _FilterForms.cache[(w.data_ptr(), tuple(w.shape))] = (w, w._version, w4.detach(), wp.detach())
+    K().poolconv3x3_weights_batch(torch.tensor(rows, dtype=torch.int64), len(rows))
 
 
 def _poolconv_weights(x_like, w):
@@ -946,6 +997,8 @@ def _poolconv_weights(x_like, w):
     K().poolconv3x3_weights(w.contiguous(), w4, wp, Cout, Cin)
     if cache is not None and w.is_contiguous():
         cache[key] = (w, w._version, w4, wp)
+        if _FilterForms.owner is not None and isinstance(w, torch.nn.Parameter):
+            _known_forms(_FilterForms.owner)[id(w)] = weakref.ref(w)
     return w4, wp
 
 

@@ -144,7 +144,7 @@ class CNNTrainer(Trainer):
         real = imgs.detach()
         if self.args.grad_penalty:
             real = real.requires_grad_()
-        with TF.filter_forms():         # the discriminator's parameters are fixed until its optimiser step
+        with TF.filter_forms(self.d):   # the discriminator's parameters are fixed until its optimiser step
             p_real, d_loss = self._d_losses(real, fake, labels)
             d_grad_penalty = None
             if self.args.grad_penalty:
@@ -230,7 +230,7 @@ class CNNTrainer(Trainer):
 
     def _g_backward(self, fake):
         """Second part (cnn.py:144-148): D(fake) with the stepped discriminator, the loss, g_loss.backward()."""
-        with TF.filter_forms():
+        with TF.filter_forms(self.d):
             g_loss = self._g_loss(fake, self._labels(len(fake))[:len(fake)])
             with TF.deferred_wgrad():
                 g_loss.backward()

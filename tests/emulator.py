@@ -71,6 +71,10 @@ class Emulator:
                 out[:, :, u, v] = acc.t()
         return 0
 
+    def upconv3x3_weights_pair(self, w, wp, w4t, Cout, Cin):
+        self.upconv3x3_weights(w, wp, Cout, Cin)
+        return self.upconv3x3_weights_t(w, w4t, Cout, Cin)
+
     def upconv3x3_dgrad_supported(self, B, Cin, Cout, H, W):
         return 1
 
@@ -184,6 +188,18 @@ class Emulator:
                 dstb = at(gbias, Cout)
                 src = at(part + 4 * E, Cout)
                 dstb.copy_(dstb + src if accumulate else src)
+        return 0
+
+    def poolconv3x3_weights_batch(self, items, n_items):
+        import ctypes
+        import numpy as np
+
+        def at(addr, n):
+            return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(addr)))
+
+        assert items.dtype == torch.int64 and tuple(items.shape) == (n_items, 5)
+        for w, w4, wp, Cout, Cin in items.tolist():
+            self.poolconv3x3_weights(at(w, Cout * Cin * 9), at(w4, Cout * Cin * 16), at(wp, Cout * Cin * 16), Cout, Cin)
         return 0
 
     def conv2d_wgrad(self, x, gy, gw, gbias, ws, ws_bytes, B, Cin, Cout, H, W, ks, accumulate):

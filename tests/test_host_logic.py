@@ -604,3 +604,49 @@ def test_adopted_rng_plan_lives_in_one_arena_with_the_latents_back_to_back():
     before = [t.clone() for t in feed.static]
     feed.static[1].fill_(7.)
     assert all(torch.equal(a, b) for k, (a, b) in enumerate(zip(before, feed.static)) if k != 1)
+
+
+def test_filter_forms_scope_for_a_module_derives_its_known_filters_in_one_launch():
+    """filter_forms(owner): the first scope learns which filters the module's pass derives; every later scope derives them all up
+    front with ONE batched call (fresh values each time: the parameters moved in between), and the results equal the per-layer path."""
+    single, batch = [], []
+
+    class Counting(Emulator):
+        def poolconv3x3_weights(self, w, w4, wp, Cout, Cin):
+            single.append(w.data_ptr())
+            return super().poolconv3x3_weights(w, w4, wp, Cout, Cin)
+
+        def poolconv3x3_weights_batch(self, items, n_items):
+            batch.append(n_items)
+            n = len(single)
+            rc = super().poolconv3x3_weights_batch(items, n_items)
+            del single[n:]                                   # (the emulator's batch entry goes through the single one)
+            return rc
+
+    backend._set_backend_for_testing(Counting())
+    torch.manual_seed(0)
+    owner = torch.nn.Module()
+    ws = [torch.nn.Parameter(torch.randn(6, 4, 3, 3) * 0.2), torch.nn.Parameter(torch.randn(5, 4, 3, 3) * 0.2),
+          torch.nn.Parameter(torch.randn(8, 4, 3, 3) * 0.2)]
+    x = torch.randn(2, 4, 16, 16)
+    ref = lambda w: torch.nn.functional.avg_pool2d(torch.nn.functional.conv2d(x, w, None, padding=1), 2)
+    with TF.filter_forms(owner):                              # learning pass: per layer, as they come
+        for w in ws:
+            TF.pool_conv3x3(x, w)
+    assert len(single) == 3 and batch == []
+    for step in range(2):
+        with torch.no_grad():
+            for w in ws:
+                w.add_(0.01)                                  # (an optimiser step between two passes)
+        with TF.filter_forms(owner):
+            outs = [TF.pool_conv3x3(x, w) for w in ws]
+            outs2 = [TF.pool_conv3x3(x, w) for w in ws]
+        assert len(single) == 3 and batch == [3] * (step + 1)  # one batched derivation, nothing per layer
+        for o, o2, w in zip(outs, outs2, ws):
+            assert torch.equal(o, o2) and torch.allclose(o, ref(w), rtol=1e-4, atol=1e-5)
+    del ws[1], w, outs, outs2, o, o2                          # a filter that no longer exists drops out of the list
+    import gc
+    gc.collect()
+    with TF.filter_forms(owner):
+        pass
+    assert batch[-1] == 2
