@@ -2418,6 +2418,25 @@ conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo,
   float bsum_a = 0.f, bsum_b[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) { acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum_b[n] = 0.f; }
+  const bool do_bias = bias_part != nullptr && (bias_mode == 0 ? blockIdx.z == 0 : blockIdx.y == 0);
+  auto products = [&](const float* pl, const float* gl, auto with_sums) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int pg = 4 * g;
+      const int goff = 2 * (pg / G::TW) * P::PWS + 2 * (pg % G::TW);
+      const float a = gl[lane_a + 4 * g];
+      float b[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[n] = pl[colbase[n] + lane_b + goff];
+      if constexpr (decltype(with_sums)::value) {
+        bsum_a += a;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bsum_b[n] += b[n];
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[n], 0, 0, 0);
+    }
+  };
   PatchStager2x<G, CKW> ps;
   GyStager<G, CT> gs;
   const int H2 = 2 * s.H, W2 = 2 * s.W;
@@ -2436,20 +2455,8 @@ conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo,
       ps.load(hi, s.B, s.Cin, H2, W2, ci0, tn, vec_hi);
       gs.load(lo, s, co0, tn, vec_lo);
     }
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int pg = 4 * g;
-      const int goff = 2 * (pg / G::TW) * P::PWS + 2 * (pg % G::TW);
-      const float a = gl[lane_a + 4 * g];
-      float b[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) b[n] = pl[colbase[n] + lane_b + goff];
-      bsum_a += a;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) bsum_b[n] += b[n];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[n], 0, 0, 0);
-    }
+    if (do_bias) products(pl, gl, std::true_type{});          // (block-uniform: the operand sums only where they are used)
+    else products(pl, gl, std::false_type{});
   }
   __syncthreads();
   float* red = lds;
@@ -2466,7 +2473,7 @@ conv_wgrad_s2_kernel(const float* __restrict__ hi, const float* __restrict__ lo,
     const int co = co0 + (l >> 4) * 4 + r, ci = ci0 + n, tap = l & 15;
     if (co < s.Cout && ci < s.Cin) part[(((int64_t)split * s.Cout + co) * s.Cin + ci) * 16 + tap] = v;
   }
-  if (bias_part != nullptr && (bias_mode == 0 ? blockIdx.z == 0 : blockIdx.y == 0)) {      // (block-uniform)
+  if (do_bias) {                                            // (block-uniform)
     __syncthreads();                                        // the partial sums above have been read out of `red`
     s2_bias_finish<NT>(red, bsum_a, bsum_b, bias_mode, bias_part, split, s.Cout, s.Cin, co0, ci0, lane, wave);
   }
@@ -2504,6 +2511,25 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
   float bsum_a = 0.f, bsum_b[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) { acc[n] = f32x4{0.f, 0.f, 0.f, 0.f}; bsum_b[n] = 0.f; }
+  const bool do_bias = bias_part != nullptr && (bias_mode == 0 ? blockIdx.z == 0 : blockIdx.y == 0);
+  auto products = [&](const float* pl, const float* gl, auto with_sums) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int pg = 4 * g;
+      const int goff = 2 * (pg / G::TW) * P::PWS + 2 * (pg % G::TW);
+      const float a = gl[lane_a + 4 * g];
+      float b[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[n] = pl[colbase[n] + lane_b + goff];
+      if constexpr (decltype(with_sums)::value) {
+        bsum_a += a;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bsum_b[n] += b[n];
+      }
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[n], 0, 0, 0);
+    }
+  };
   const int cvalid = min(CKW, s.Cin - ci0);
   for (int t = split; t < ntiles; t += S) {
     const TileCoord tc = decode_tile<G>(t, s.H, s.W);
@@ -2541,20 +2567,8 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
     const float* pl = lds;
     const float* gl = lds + PBUF;
     if (s.prio) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int pg = 4 * g;
-      const int goff = 2 * (pg / G::TW) * P::PWS + 2 * (pg % G::TW);
-      const float a = gl[lane_a + 4 * g];
-      float b[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) b[n] = pl[colbase[n] + lane_b + goff];
-      bsum_a += a;
-#pragma unroll
-      for (int n = 0; n < NT; ++n) bsum_b[n] += b[n];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[n], acc[n], 0, 0, 0);
-    }
+    if (do_bias) products(pl, gl, std::true_type{});          // (block-uniform: the operand sums only where they are used)
+    else products(pl, gl, std::false_type{});
     if (s.prio) __builtin_amdgcn_s_setprio(3);
   }
   __syncthreads();
@@ -2572,7 +2586,7 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
     const int co = co0 + (l >> 4) * 4 + r, ci = ci0 + n, tap = l & 15;
     if (co < s.Cout && ci < s.Cin) part[(((int64_t)split * s.Cout + co) * s.Cin + ci) * 16 + tap] = v;
   }
-  if (bias_part != nullptr && (bias_mode == 0 ? blockIdx.z == 0 : blockIdx.y == 0)) {      // (block-uniform)
+  if (do_bias) {                                            // (block-uniform)
     __syncthreads();                                        // the partial sums above have been read out of `red`
     s2_bias_finish<NT>(red, bsum_a, bsum_b, bias_mode, bias_part, split, s.Cout, s.Cin, co0, ci0, lane, wave);
   }

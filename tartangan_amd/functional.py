@@ -960,7 +960,20 @@ _KNOWN_FORMS = weakref.WeakKeyDictionary()       # module -> {id(weight): weakre
 
 
 def _known_forms(owner):
-    return _KNOWN_FORMS.setdefault(owner, {})
+    known = _KNOWN_FORMS.get(owner)
+    if known is None:
+        # start from the module's structure: every ``Sequential`` that ends in conv3x3 -> AvgPool2d(2) is a candidate for the
+        # stride-2 form (models.layers.run_layers decides per call, by shape); the per-scope learning below adds whatever
+        # else derives a filter.  So the very first pass -- the one a HIP graph is captured from -- already batches.
+        known = _KNOWN_FORMS[owner] = {}
+        for m in owner.modules():
+            if isinstance(m, torch.nn.Sequential) and len(m) >= 2:
+                conv, pool = m[len(m) - 2], m[len(m) - 1]
+                w = getattr(conv, 'weight', None)
+                if (type(pool).__name__ == 'AvgPool2d' and isinstance(w, torch.nn.Parameter) and w.dim() == 4
+                        and tuple(w.shape[2:]) == (3, 3)):
+                    known[id(w)] = weakref.ref(w)
+    return known
 
 
 def _derive_known_forms(owner):
