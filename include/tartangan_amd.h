@@ -291,6 +291,10 @@ int tg_row_bcast(const float* v, float* out, float alpha, int rows, int cols, vo
 int tg_repeat_rows(const float* x, float* out, float alpha, int rows, int cols, int reps, void* stream);
 /* out[r][c] = alpha * sum_q x[q*rows + r][c]  (p_target_tau.mean(0), discriminator.py:174-175) */
 int tg_sum_reps(const float* x, float* out, float alpha, int rows, int cols, int reps, void* stream);
+/* the same over `groups` independent row blocks back to back (x: groups x rows rows; the repeated side: groups x reps x rows): the
+ * real and the fake batch of a discriminator step through the IQN head as one tensor, each half repeated / averaged on its own */
+int tg_repeat_rows_groups(const float* x, float* out, float alpha, int rows, int cols, int reps, int groups, void* stream);
+int tg_sum_reps_groups(const float* x, float* out, float alpha, int rows, int cols, int reps, int groups, void* stream);
 
 /* ---------------------------------------------------------------- elementwise */
 int tg_add(const float* a, const float* b, float* out, int64_t n, void* stream);
@@ -369,6 +373,10 @@ int tg_iqn_cos_embed(const float* taus, const float* range, float* out, int n, i
  * *loss = sum_q,b |tau - 1[err<0]| * huber_k(err) / B ; dpreds = d loss / d preds       */
 int tg_iqn_loss(const float* preds, const float* target, const float* taus, float k,
                 float* loss, float* dpreds, float* workspace, int Q, int B, void* stream);
+/* `groups` evaluations back to back (preds / taus rows g*Q*B + q*B + b, target rows g*B + b): *loss = the SUM of their losses
+ * (trainers/iqn.py:118-120: loss_real + loss_fake), dpreds per evaluation as above */
+int tg_iqn_loss_groups(const float* preds, const float* target, const float* taus, float k,
+                       float* loss, float* dpreds, float* workspace, int Q, int B, int groups, void* stream);
 
 /* ---------------------------------------------------------------- losses
  * nn.BCEWithLogitsLoss (mean) trainers/cnn.py:88,131,147; dlogits = (sigmoid(x)-t)/n    */

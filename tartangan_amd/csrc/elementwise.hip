@@ -213,14 +213,15 @@ __global__ void __launch_bounds__(RED_BLOCK) bce_stage1(const float* __restrict_
 // IQN quantile Huber loss (models/iqn.py:111-130), out_dims = 1, row = q*B + b
 __global__ void __launch_bounds__(RED_BLOCK) iqn_loss_stage1(const float* __restrict__ preds, const float* __restrict__ target,
                                                              const float* __restrict__ taus, float k, float* __restrict__ dpreds,
-                                                             double* __restrict__ partial, int Q, int B) {
+                                                             double* __restrict__ partial, int Q, int B, int G) {
+  // G independent evaluations back to back (rows g*Q*B + q*B + b, targets g*B + b): the sum of their losses
   __shared__ double scratch[32];
   double acc = 0.0;
   const int n = Q * B;
   const float inv_b = 1.f / (float)B;
-  for (int i = blockIdx.x * RED_BLOCK + threadIdx.x; i < n; i += gridDim.x * RED_BLOCK) {
-    const int b = i % B;
-    const float err = target[b] - preds[i];
+  for (int i = blockIdx.x * RED_BLOCK + threadIdx.x; i < n * G; i += gridDim.x * RED_BLOCK) {
+    const int g = i / n, b = (i - g * n) % B;
+    const float err = target[g * B + b] - preds[i];
     const float a = fabsf(err);
     const bool quad = a <= k;
     const float hub = quad ? 0.5f * err * err : k * (a - 0.5f * k);
@@ -338,15 +339,19 @@ int tg_bce_logits(const float* logits, const float* targets, float* loss, float*
   return tg_launch_status();
 }
 
-int tg_iqn_loss(const float* preds, const float* target, const float* taus, float k, float* loss, float* dpreds,
-                float* workspace, int Q, int B, void* stream) {
+int tg_iqn_loss_groups(const float* preds, const float* target, const float* taus, float k, float* loss, float* dpreds,
+                       float* workspace, int Q, int B, int groups, void* stream) {
   TG_CHECK_PTR(preds); TG_CHECK_PTR(target); TG_CHECK_PTR(taus); TG_CHECK_PTR(loss); TG_CHECK_PTR(dpreds); TG_CHECK_PTR(workspace);
-  TG_CHECK_POS(Q); TG_CHECK_POS(B);
+  TG_CHECK_POS(Q); TG_CHECK_POS(B); TG_CHECK_POS(groups);
   double* partial = reinterpret_cast<double*>(workspace);
-  const int g = red_grid((int64_t)Q * B);
-  iqn_loss_stage1<<<g, RED_BLOCK, 0, tg_stream(stream)>>>(preds, target, taus, k, dpreds, partial, Q, B);
+  const int g = red_grid((int64_t)Q * B * groups);
+  iqn_loss_stage1<<<g, RED_BLOCK, 0, tg_stream(stream)>>>(preds, target, taus, k, dpreds, partial, Q, B, groups);
   reduce_stage2<<<1, RED_BLOCK, 0, tg_stream(stream)>>>(partial, g, 1.0 / (double)B, loss);
   return tg_launch_status();
+}
+int tg_iqn_loss(const float* preds, const float* target, const float* taus, float k, float* loss, float* dpreds,
+                float* workspace, int Q, int B, void* stream) {
+  return tg_iqn_loss_groups(preds, target, taus, k, loss, dpreds, workspace, Q, B, 1, stream);
 }
 
 int tg_iqn_cos_embed(const float* taus, const float* range, float* out, int n, int dims, void* stream) {

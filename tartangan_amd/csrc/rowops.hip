@@ -61,20 +61,22 @@ __global__ void __launch_bounds__(RB) row_bcast_kernel(const float* __restrict__
     out[i] = alpha * v[i / cols];
 }
 
-// out[q*rows*cols + i] = alpha * x[i]
+// out[(g*reps + q)*rc + w] = alpha * x[g*rc + w]: x is G groups of `rows` rows, each group repeated on its own (G = 1: x.repeat(reps, 1))
 __global__ void __launch_bounds__(RB) repeat_rows_kernel(const float* __restrict__ x, float* __restrict__ out, float alpha,
-                                                         int64_t rc, int reps) {
-  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < rc; i += gridDim.x * (int64_t)RB) {
+                                                         int64_t rc, int reps, int groups) {
+  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < rc * groups; i += gridDim.x * (int64_t)RB) {
+    const int64_t g = i / rc, w = i - g * rc;
     const float v = alpha * x[i];
-    for (int q = 0; q < reps; ++q) out[(int64_t)q * rc + i] = v;
+    for (int q = 0; q < reps; ++q) out[(g * reps + q) * rc + w] = v;
   }
 }
 
 __global__ void __launch_bounds__(RB) sum_reps_kernel(const float* __restrict__ x, float* __restrict__ out, float alpha,
-                                                      int64_t rc, int reps) {
-  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < rc; i += gridDim.x * (int64_t)RB) {
+                                                      int64_t rc, int reps, int groups) {
+  for (int64_t i = blockIdx.x * (int64_t)RB + threadIdx.x; i < rc * groups; i += gridDim.x * (int64_t)RB) {
+    const int64_t g = i / rc, w = i - g * rc;
     float acc = 0.f;
-    for (int q = 0; q < reps; ++q) acc += x[(int64_t)q * rc + i];
+    for (int q = 0; q < reps; ++q) acc += x[(g * reps + q) * rc + w];
     out[i] = alpha * acc;
   }
 }
@@ -213,18 +215,24 @@ int tg_row_bcast(const float* v, float* out, float alpha, int rows, int cols, vo
   return tg_launch_status();
 }
 
-int tg_repeat_rows(const float* x, float* out, float alpha, int rows, int cols, int reps, void* stream) {
-  TG_CHECK_PTR(x); TG_CHECK_PTR(out); TG_CHECK_POS(rows); TG_CHECK_POS(cols); TG_CHECK_POS(reps);
+int tg_repeat_rows_groups(const float* x, float* out, float alpha, int rows, int cols, int reps, int groups, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(out); TG_CHECK_POS(rows); TG_CHECK_POS(cols); TG_CHECK_POS(reps); TG_CHECK_POS(groups);
   const int64_t rc = (int64_t)rows * cols;
-  repeat_rows_kernel<<<tg_ew_grid(rc, RB), RB, 0, tg_stream(stream)>>>(x, out, alpha, rc, reps);
+  repeat_rows_kernel<<<tg_ew_grid(rc * groups, RB), RB, 0, tg_stream(stream)>>>(x, out, alpha, rc, reps, groups);
   return tg_launch_status();
 }
+int tg_repeat_rows(const float* x, float* out, float alpha, int rows, int cols, int reps, void* stream) {
+  return tg_repeat_rows_groups(x, out, alpha, rows, cols, reps, 1, stream);
+}
 
-int tg_sum_reps(const float* x, float* out, float alpha, int rows, int cols, int reps, void* stream) {
-  TG_CHECK_PTR(x); TG_CHECK_PTR(out); TG_CHECK_POS(rows); TG_CHECK_POS(cols); TG_CHECK_POS(reps);
+int tg_sum_reps_groups(const float* x, float* out, float alpha, int rows, int cols, int reps, int groups, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(out); TG_CHECK_POS(rows); TG_CHECK_POS(cols); TG_CHECK_POS(reps); TG_CHECK_POS(groups);
   const int64_t rc = (int64_t)rows * cols;
-  sum_reps_kernel<<<tg_ew_grid(rc, RB), RB, 0, tg_stream(stream)>>>(x, out, alpha, rc, reps);
+  sum_reps_kernel<<<tg_ew_grid(rc * groups, RB), RB, 0, tg_stream(stream)>>>(x, out, alpha, rc, reps, groups);
   return tg_launch_status();
+}
+int tg_sum_reps(const float* x, float* out, float alpha, int rows, int cols, int reps, void* stream) {
+  return tg_sum_reps_groups(x, out, alpha, rows, cols, reps, 1, stream);
 }
 
 int tg_softmax_fwd(const float* s, float* y, int rows, int cols, void* stream) {

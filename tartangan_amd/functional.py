@@ -1748,42 +1748,63 @@ PAIR_SPECS[_RowSum] = ('b--', '', 'b')          # (only for reductions that keep
 
 
 class _RepeatRows(Function):
+    """x.repeat(reps, 1) -- for ``groups`` row blocks back to back, each repeated on its own (tg_repeat_rows_groups)."""
+
     @staticmethod
-    def forward(ctx, x, reps, alpha):
+    def forward(ctx, x, reps, alpha, groups=1):
         x = x.contiguous()
-        rows, cols = x.shape
-        out = x.new_empty(rows * reps, cols)
-        K().repeat_rows(x, out, alpha, rows, cols, reps)
-        ctx.reps, ctx.alpha = reps, alpha
+        rows, cols = x.shape[0] // groups, x.shape[1]
+        out = x.new_empty(groups * rows * reps, cols)
+        K().repeat_rows_groups(x, out, alpha, rows, cols, reps, groups)
+        ctx.reps, ctx.alpha, ctx.groups = reps, alpha, groups
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return _SumReps.apply(g, ctx.reps, ctx.alpha), None, None
+        return _SumReps.apply(g, ctx.reps, ctx.alpha, ctx.groups), None, None, None
+
+    @staticmethod
+    def pair_full(fargs):
+        return fargs[:3] + [2]
+
+    @staticmethod
+    def pair_half(sub):
+        sub.groups = 1
 
 
 class _SumReps(Function):
     @staticmethod
-    def forward(ctx, x, reps, alpha):
+    def forward(ctx, x, reps, alpha, groups=1):
         x = x.contiguous()
-        rows, cols = x.shape[0] // reps, x.shape[1]
-        out = x.new_empty(rows, cols)
-        K().sum_reps(x, out, alpha, rows, cols, reps)
-        ctx.reps, ctx.alpha = reps, alpha
+        rows, cols = x.shape[0] // (reps * groups), x.shape[1]
+        out = x.new_empty(groups * rows, cols)
+        K().sum_reps_groups(x, out, alpha, rows, cols, reps, groups)
+        ctx.reps, ctx.alpha, ctx.groups = reps, alpha, groups
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return _RepeatRows.apply(g, ctx.reps, ctx.alpha), None, None
+        return _RepeatRows.apply(g, ctx.reps, ctx.alpha, ctx.groups), None, None, None
+
+    pair_full = _RepeatRows.pair_full
+    pair_half = _RepeatRows.pair_half
+
+
+PAIR_SPECS[_RepeatRows] = ('b---', '', 'b')
+PAIR_SPECS[_SumReps] = ('b---', '', 'b')
 
 
 def repeat_rows(x, reps):
-    """x.repeat(reps, 1)"""
+    """x.repeat(reps, 1); a Pair: each half repeated on its own (rows stay [half][rep][row])"""
+    if _is_pair(x):
+        return pair_apply(_RepeatRows, x, reps, 1.0, 1)
     return _RepeatRows.apply(x, reps, 1.0)
 
 
 def mean_reps(x, reps):
     """x.reshape(reps, -1, cols).mean(0)"""
+    if _is_pair(x):
+        return pair_apply(_SumReps, x, reps, 1.0 / reps, 1)
     return _SumReps.apply(x, reps, 1.0 / reps)
 
 
@@ -1877,7 +1898,12 @@ class _Mul(Function):
 
 
 def mul(a, b):
+    if _is_pair(a) or _is_pair(b):
+        return pair_apply(_Mul, a, b)
     return _Mul.apply(a, b)
+
+
+PAIR_SPECS[_Mul] = ('bb', 'hh', 'b')
 
 
 class _Scale(Function):
@@ -2321,6 +2347,10 @@ PAIR_SPECS[_AttnCore] = ('bbb', 'hhhhh', 'b')
 # =========================================================================== IQN / losses
 def iqn_cos_embed(taus, embedding_range):
     """cos((tau*pi)*range) -- no gradient (taus are sampled, range is a buffer)."""
+    if _is_pair(taus):
+        both = iqn_cos_embed(_join(taus.r.contiguous(), taus.f.contiguous()), embedding_range)
+        n = both.shape[0] // 2
+        return Pair(both[:n], both[n:])
     taus = taus.contiguous()
     n, dims = taus.shape[0], embedding_range.shape[0]
     out = taus.new_empty(n, dims)
@@ -2346,25 +2376,37 @@ class _ScaledGrad(Function):
 
 
 class _IQNLoss(Function):
+    """models/iqn.py:111-130; ``groups`` evaluations back to back: the SUM of their losses (tg_iqn_loss_groups)."""
+
     @staticmethod
-    def forward(ctx, preds, target, taus, num_quantiles, k):
+    def forward(ctx, preds, target, taus, num_quantiles, k, groups=1):
         pc, target, taus = preds.contiguous(), target.contiguous(), taus.contiguous()
-        B = target.shape[0]
+        B = target.shape[0] // groups
         loss = pc.new_empty(())
         dpreds = torch.empty_like(pc)
         ws = _ws(pc, K().reduce_workspace(pc.numel()))
-        K().iqn_loss(pc, target, taus, float(k), loss, dpreds, ws, num_quantiles, B)
+        K().iqn_loss_groups(pc, target, taus, float(k), loss, dpreds, ws, num_quantiles, B, groups)
         _ScaledGrad._finish(ctx, preds, dpreds)
         return loss
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        return _ScaledGrad._bwd(ctx, g), None, None, None, None
+        return _ScaledGrad._bwd(ctx, g), None, None, None, None, None
+
+    @staticmethod
+    def pair_full(fargs):
+        return fargs[:5] + [2]
+
+
+PAIR_SPECS[_IQNLoss] = ('b-b---', 'h', '-')
 
 
 def iqn_quantile_huber_loss(preds, target, taus, num_quantiles, k=1.0):
-    """models/iqn.py:111-130 for out_dims == 1 (preds/taus (Q*B,1), row = q*B + b)."""
+    """models/iqn.py:111-130 for out_dims == 1 (preds/taus (Q*B,1), row = q*B + b).  ``preds`` / ``taus`` Pairs (``target``: the
+    (2B, 1) targets of both halves): loss_real + loss_fake (trainers/iqn.py:118-120) from one launch."""
+    if _is_pair(preds):
+        return pair_apply(_IQNLoss, preds, target, taus, num_quantiles, k, 1)
     return _IQNLoss.apply(preds, target, taus, num_quantiles, k)
 
 

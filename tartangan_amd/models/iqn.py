@@ -41,9 +41,17 @@ class IQN(nn.Module):
         return state
 
     def forward(self, x):
-        batch_size = x.shape[0]
-        x = TF.repeat_rows(x, self.num_quantiles)               # (Q*B, C), row = q*B + b
-        quantiles = self.sample_quantiles(batch_size)           # (Q*B, 1)
+        if isinstance(x, TF.Pair):
+            # the real and the fake batch of a discriminator step as one tensor: rows [half][q][b]; each evaluation draws its
+            # own taus, real first (trainers/iqn.py:118-119 are two calls)
+            batch_size = x.r.shape[0]
+            x = TF.repeat_rows(x, self.num_quantiles)
+            q_real = self.sample_quantiles(batch_size)
+            quantiles = TF.Pair(q_real, self.sample_quantiles(batch_size))
+        else:
+            batch_size = x.shape[0]
+            x = TF.repeat_rows(x, self.num_quantiles)               # (Q*B, C), row = q*B + b
+            quantiles = self.sample_quantiles(batch_size)           # (Q*B, 1)
         emb = self.quantile_embedding(quantiles)
         if self.mix == 'add':
             return TF.add(x, emb), quantiles
@@ -60,7 +68,8 @@ class IQN(nn.Module):
 
 
 def iqn_loss(preds, target, taus, k=1.):
+    """A Pair of predictions (with the (2B, .) targets of both halves): the sum of the two evaluations' losses."""
     assert not target.requires_grad
     batch_size = target.shape[0]
-    num_quantiles = preds.shape[0] // batch_size
+    num_quantiles = preds.shape[0] // batch_size           # (Pair.shape counts both halves, like target)
     return TF.iqn_quantile_huber_loss(preds, target.reshape(batch_size, -1), taus, num_quantiles, k)

@@ -120,16 +120,9 @@ class IQNDiscriminator(Discriminator):
         self.blocks = nn.Sequential(*stages)
 
     def forward(self, x, targets=None):
-        if isinstance(x, TF.Pair):
-            # real | fake as one batch through the blocks; the IQN head runs per half (its rows are quantile-major per
-            # evaluation, and each evaluation draws its own taus: real first, then fake -- iqn.py:118-119)
-            feats = self.blocks(x)
-            n = feats.r.shape[0]
-            out_r = self.to_output(feats.r, targets=None if targets is None else targets[:n])
-            out_f = self.to_output(feats.f, targets=None if targets is None else targets[n:])
-            if targets is None:
-                return TF.Pair(out_r, out_f)
-            return TF.Pair(out_r[0], out_f[0]), (out_r[1], out_f[1])
+        # a Pair (real | fake as one batch): blocks and head alike on 2B images; the head keeps each half's rows quantile-major
+        # on their own and draws each half's taus separately, real first (iqn.py:118-119); with targets (2B, 1) its loss is
+        # loss_real + loss_fake
         return self.to_output(self.blocks(x), targets=targets)
 
 

@@ -19,8 +19,8 @@ class IQNTrainer(CNNTrainer):
     def _d_losses(self, real, fake, labels):
         bs = len(real)
         if self._d_pairable():
-            p, (loss_real, loss_fake) = self.d(TF.Pair(real, fake), targets=labels)      # blocks on 2B images, heads per half
-            return p.r, TF.add(loss_real, loss_fake)
+            p, d_loss = self.d(TF.Pair(real, fake), targets=labels)      # blocks and head on 2B images: loss_real + loss_fake
+            return p.r, d_loss
         p_real, loss_real = self.d(real, targets=labels[:bs])     # taus drawn here (8B) ...
         _, loss_fake = self.d(fake, targets=labels[bs:])           # ... then here (8B)
         return p_real, TF.add(loss_real, loss_fake)

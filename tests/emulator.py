@@ -520,6 +520,14 @@ class Emulator:
         _v(out, rows, cols).copy_(alpha * _v(x, reps, rows, cols).sum(0))
         return 0
 
+    def repeat_rows_groups(self, x, out, alpha, rows, cols, reps, groups):
+        _v(out, groups, reps, rows, cols).copy_(alpha * _v(x, groups, 1, rows, cols).expand(groups, reps, rows, cols))
+        return 0
+
+    def sum_reps_groups(self, x, out, alpha, rows, cols, reps, groups):
+        _v(out, groups, rows, cols).copy_(alpha * _v(x, groups, reps, rows, cols).sum(1))
+        return 0
+
     # ---------------------------------------------------------------- elementwise
     def add(self, a, b, out, n):
         out.copy_(a + b)
@@ -674,6 +682,17 @@ class Emulator:
         wgt = (taus.view(Q, B) - (err < 0).float()).abs()
         loss.copy_((wgt * hub).sum(0).mean())
         dpreds.view(Q, B).copy_(-wgt * dhub / B)
+        return 0
+
+    def iqn_loss_groups(self, preds, target, taus, k, loss, dpreds, ws, Q, B, groups):
+        total = torch.zeros(())
+        one = torch.zeros(())
+        for g in range(groups):
+            rows = slice(g * Q * B, (g + 1) * Q * B)
+            self.iqn_loss(preds.reshape(-1)[rows], target.reshape(-1)[g * B:(g + 1) * B], taus.reshape(-1)[rows], k, one,
+                          dpreds.view(-1)[rows], ws, Q, B)
+            total = total + one
+        loss.copy_(total)
         return 0
 
     def bce_logits(self, logits, targets, loss, dlogits, ws, n):

@@ -561,6 +561,9 @@ def test_row_and_channel_ops(K):
     run_both(K, 'row_bcast', [rnd(B * C), torch.zeros(B * C, HW), 0.5, B * C, HW], [1], tol=1e-6)
     run_both(K, 'repeat_rows', [rnd(7, 9), torch.zeros(8 * 7, 9), 1.0, 7, 9, 8], [1], atol=0.0)
     run_both(K, 'sum_reps', [rnd(8 * 7, 9), torch.zeros(7, 9), 0.125, 7, 9, 8], [1], tol=1e-6)
+    # two row blocks back to back, each repeated / averaged on its own (the real and the fake half through the IQN head)
+    run_both(K, 'repeat_rows_groups', [rnd(2 * 7, 9), torch.zeros(2 * 8 * 7, 9), 1.0, 7, 9, 8, 2], [1], atol=0.0)
+    run_both(K, 'sum_reps_groups', [rnd(2 * 8 * 7, 9), torch.zeros(2 * 7, 9), 0.125, 7, 9, 8, 2], [1], tol=1e-6)
 
 
 def test_elementwise(K):
@@ -694,6 +697,10 @@ def test_iqn_and_losses(K):
     target = (torch.arange(B) % 2).float().view(B, 1)
     ws = workspace(K.reduce_workspace(Q * B))
     run_both(K, 'iqn_loss', [preds, target, taus, 1.0, torch.zeros(()), torch.zeros(Q * B, 1), ws, Q, B], [4, 5], tol=2e-6)
+    # two evaluations back to back: the sum of their losses, each over its own rows / targets / taus
+    preds2, taus2 = torch.cat([preds, rnd(Q * B, 1, seed=7) * 2]), torch.cat([taus, torch.rand(Q * B, 1)])
+    target2 = torch.cat([target, 1 - target])
+    run_both(K, 'iqn_loss_groups', [preds2, target2, taus2, 1.0, torch.zeros(()), torch.zeros(2 * Q * B, 1), ws, Q, B, 2], [4, 5], tol=2e-6)
     logits, t = rnd(48, 1) * 4, (torch.arange(48) % 2).float().view(48, 1)
     run_both(K, 'bce_logits', [logits, t, torch.zeros(()), torch.zeros(48, 1), ws, 48], [2, 3], tol=2e-6)
 

@@ -139,3 +139,49 @@ def test_bce_over_a_pair_is_the_loss_over_the_concatenation():
     assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
     for a, b in zip(torch.autograd.grad(got, [pr, pf]), torch.autograd.grad(want, [pr, pf])):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+# ---- the IQN head's row ops: a Pair keeps each half's rows quantile-major on their own ([half][q][b])
+def _rows(seed):
+    return _t(B, 5, seed=seed)
+
+
+@pytest.mark.parametrize('name,fn', [('repeat_rows', lambda x: TF.repeat_rows(x, 3)),
+                                     ('repeat+mean', lambda x: TF.mean_reps(TF.tanh(TF.repeat_rows(x, 3)), 3)),
+                                     ('mul', lambda x: TF.mul(TF.repeat_rows(x, 2), TF.tanh(TF.repeat_rows(x, 2))))])
+def test_paired_row_ops_of_the_iqn_head(name, fn):
+    xr, xf = _rows(41), _rows(42)
+    out, sep_r, sep_f = fn(TF.Pair(xr, xf)), fn(xr), fn(xf)
+    assert torch.allclose(out.r, sep_r, rtol=1e-6, atol=1e-7) and torch.allclose(out.f, sep_f, rtol=1e-6, atol=1e-7)
+    assert out.f.data_ptr() == out.r.data_ptr() + out.r.numel() * 4
+    wr, wf = torch.randn_like(sep_r), torch.randn_like(sep_f)
+    for cr, cf in ((1.0, 1.0), (1.0, 0.0), (0.0, 1.0)):
+        got = torch.autograd.grad(sum((o * w).sum() for o, w, c in ((out.r, wr, cr), (out.f, wf, cf)) if c), [xr, xf],
+                                  retain_graph=True, allow_unused=True)
+        want = torch.autograd.grad(sum((o * w).sum() for o, w, c in ((sep_r, wr, cr), (sep_f, wf, cf)) if c), [xr, xf],
+                                   retain_graph=True, allow_unused=True)
+        for a, b in zip(got, want):
+            assert (a is None and b is None) or torch.allclose(a, b, rtol=1e-5, atol=1e-6), (name, cr, cf)
+    # second derivative through the first half (the R1 penalty differentiates the quantile-mean prediction)
+    vals = []
+    for paired in (True, False):
+        o = fn(TF.Pair(xr, xf)).r if paired else fn(xr)
+        g, = torch.autograd.grad((o * o).sum(), xr, create_graph=True)
+        vals.append(torch.autograd.grad((g * g).sum(), xr)[0])
+    assert torch.allclose(vals[0], vals[1], rtol=1e-4, atol=1e-6), name
+
+
+def test_iqn_loss_over_a_pair_is_the_sum_of_the_two_evaluations():
+    """trainers/iqn.py:118-120: loss_real + loss_fake, each over its own quantile-major rows and its own taus."""
+    Q = 4
+    pr, pf = _t(Q * B, 1, seed=51), _t(Q * B, 1, seed=52)
+    tr, tf = torch.rand(Q * B, 1), torch.rand(Q * B, 1)
+    targets = torch.cat([torch.ones(B, 1), torch.zeros(B, 1)])
+    got = TF.iqn_quantile_huber_loss(TF.Pair(pr, pf), targets, TF.Pair(tr, tf), Q)
+    want = TF.iqn_quantile_huber_loss(pr, targets[:B], tr, Q) + TF.iqn_quantile_huber_loss(pf, targets[B:], tf, Q)
+    assert torch.allclose(got, want, rtol=1e-6, atol=1e-7)
+    for a, b in zip(torch.autograd.grad(got, [pr, pf]), torch.autograd.grad(want, [pr, pf])):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
+    emb = TF.iqn_cos_embed(TF.Pair(tr, tf), torch.arange(1, 7).float())
+    assert torch.equal(emb.r, TF.iqn_cos_embed(tr, torch.arange(1, 7).float()))
+    assert torch.equal(emb.f, TF.iqn_cos_embed(tf, torch.arange(1, 7).float()))

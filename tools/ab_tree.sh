@@ -3,8 +3,8 @@ set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for round in 1 2; do
-  (cd ab_old && timeout -k 10 400 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-kernel-timing) > gpurun_out/ab_old_$round.json 2> gpurun_out/ab_old_$round.err
-  timeout -k 10 400 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-kernel-timing > gpurun_out/ab_new_$round.json 2> gpurun_out/ab_new_$round.err
+  (cd ab_old && timeout -k 10 400 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-kernel-timing "$@") > gpurun_out/ab_old_$round.json 2> gpurun_out/ab_old_$round.err
+  timeout -k 10 400 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-kernel-timing "$@" > gpurun_out/ab_new_$round.json 2> gpurun_out/ab_new_$round.err
 done
 python - <<'PY'
 import json, glob
