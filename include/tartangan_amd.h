@@ -141,6 +141,16 @@ int tg_conv2d_wgrad_reduce_batch(const tg_host_i64* items /*host*/, int n_items,
  * [3] Cout  [4] Cin.  Same arithmetic per layer as the single call. */
 #define TG_FORM_ITEM_FIELDS 5
 int tg_poolconv3x3_weights_batch(const tg_host_i64* items /*host*/, int n_items, void* stream);
+/* The stride-2 weight gradients in two steps, like tg_conv2d_wgrad_partials / _reduce_batch: stage 1 per layer into a workspace of its
+ * own (tg_*_wgrad_workspace bytes, untouched until the reduce has run), then ONE launch that sums, folds onto the 3x3 taps and
+ * finishes the bias gradients of all recorded layers.  Items as for tg_conv2d_wgrad_reduce_batch with [8] = 0 (pooled conv: stage 1
+ * by tg_poolconv3x3_wgrad_partials) or 1 (up-conv: tg_upconv3x3_wgrad_partials) in the place of ks; (B, ., H, W) the LOW-resolution
+ * plane; [2] gbias nonzero needs want_bias != 0 in stage 1.  Bit-identical to the one-call forms.                               */
+int tg_poolconv3x3_wgrad_partials(const float* x, const float* gy, float* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
+                                  int H, int W, int want_bias, void* stream);
+int tg_upconv3x3_wgrad_partials(const float* a, const float* gy, float* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
+                                int H, int W, int want_bias, void* stream);
+int tg_s2_wgrad_reduce_batch(const tg_host_i64* items /*host*/, int n_items, void* stream);
 /* out[c] (+)= sum_{b,p} x[b][c][p]   (linear bias grad); workspace: tg_bn_workspace(B,C,HW) bytes */
 int tg_channel_sum(const float* x, float* out, float* workspace, int B, int C, int HW, int accumulate,
                    void* stream);

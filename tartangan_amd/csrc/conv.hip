@@ -2596,13 +2596,13 @@ conv_wgrad_s2_dma_kernel(const float* __restrict__ hi, const float* __restrict__
 // channel pairs; thread = (pair, tap, S-slice), the 4 slices are combined through LDS, then 9 threads per pair fold.
 //   mode 0 (pooled conv, T[co][ci]):  gw[kh][kw] (+)= 0.25 sum_{dy,dx} T[dy+kh][dx+kw];
 //   mode 1 (up-conv, T[ci][co]):      gw[kh][kw] (+)= sum_{u: kh in S(u)} sum_{v: kw in S(v)} T[u][v], S = {2},{1,2},{0,1},{0}.
-__global__ void __launch_bounds__(256) s2wgrad_reduce_fold_kernel(const float* __restrict__ part, float* __restrict__ gw, int S, int Clo,
-                                                                  int Chi, int Cout, int Cin, int mode, int accumulate,
-                                                                  const float* __restrict__ bias_part /*nullable: [S][Cout]*/,
-                                                                  float* __restrict__ gbias, int pair_blocks) {
-  if ((int)blockIdx.x >= pair_blocks) {
+__device__ __forceinline__ void s2wgrad_reduce_fold(const float* __restrict__ part, float* __restrict__ gw, int S, int Clo, int Chi,
+                                                    int Cout, int Cin, int mode, int accumulate,
+                                                    const float* __restrict__ bias_part /*nullable: [S][Cout]*/, float* __restrict__ gbias,
+                                                    int pair_blocks, int bx /*block index within this layer's blocks*/) {
+  if (bx >= pair_blocks) {
     // the bias gradient: one wave per channel, lanes stride over the S partials, fixed-order wavefront sum
-    const int c = ((int)blockIdx.x - pair_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = (bx - pair_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= Cout) return;                        // (whole wave)
     float v = 0.f;
     for (int sidx = lane; sidx < S; sidx += 64) v += bias_part[(int64_t)sidx * Cout + c];
@@ -2615,7 +2615,7 @@ __global__ void __launch_bounds__(256) s2wgrad_reduce_fold_kernel(const float* _
   __shared__ float T[4][16];
   const int tap = threadIdx.x & 15, pr = (threadIdx.x >> 4) & 3, sl = threadIdx.x >> 6;
   const int64_t npairs = (int64_t)Clo * Chi;
-  const int64_t pair = (int64_t)blockIdx.x * 4 + pr;    // index into T's [lo][hi] layout
+  const int64_t pair = (int64_t)bx * 4 + pr;    // index into T's [lo][hi] layout
   float a0 = 0.f, a1 = 0.f;
   if (pair < npairs) {
     const float* src = part + pair * 16 + tap;
@@ -2630,7 +2630,7 @@ __global__ void __launch_bounds__(256) s2wgrad_reduce_fold_kernel(const float* _
   __syncthreads();
   if (threadIdx.x < 36) {
     const int p = threadIdx.x / 9, k = threadIdx.x % 9, kh = k / 3, kw = k % 3;
-    const int64_t pp = (int64_t)blockIdx.x * 4 + p;
+    const int64_t pp = (int64_t)bx * 4 + p;
     if (pp < npairs) {
       const int lo = (int)(pp / Chi), hi = (int)(pp % Chi);
       const int co = mode == 0 ? lo : hi, ci = mode == 0 ? hi : lo;
@@ -2641,6 +2641,25 @@ __global__ void __launch_bounds__(256) s2wgrad_reduce_fold_kernel(const float* _
       *o = accumulate ? *o + r : r;
     }
   }
+}
+
+__global__ void __launch_bounds__(256) s2wgrad_reduce_fold_kernel(const float* __restrict__ part, float* __restrict__ gw, int S, int Clo,
+                                                                  int Chi, int Cout, int Cin, int mode, int accumulate,
+                                                                  const float* __restrict__ bias_part, float* __restrict__ gbias,
+                                                                  int pair_blocks) {
+  s2wgrad_reduce_fold(part, gw, S, Clo, Chi, Cout, Cin, mode, accumulate, bias_part, gbias, pair_blocks, (int)blockIdx.x);
+}
+// ... for the stride-2 layers of a whole backward pass in one launch (tg_s2_wgrad_reduce_batch)
+constexpr int SB_MAX_ITEMS = 16;
+struct FoldItem { const float* part; float* gw; const float* bias_part; float* gbias; int S, Clo, Chi, Cout, Cin, mode, accumulate, pair_blocks; };
+struct FoldBatch { FoldItem item[SB_MAX_ITEMS]; int block_end[SB_MAX_ITEMS]; int n; };
+__global__ void __launch_bounds__(256) s2wgrad_reduce_fold_batch_kernel(FoldBatch fb) {
+  int i = 0;
+  while (i + 1 < fb.n && (int)blockIdx.x >= fb.block_end[i]) ++i;            // (block-uniform)
+  const int first = i == 0 ? 0 : fb.block_end[i - 1];
+  const FoldItem& it = fb.item[i];
+  s2wgrad_reduce_fold(it.part, it.gw, it.S, it.Clo, it.Chi, it.Cout, it.Cin, it.mode, it.accumulate, it.bias_part, it.gbias,
+                      it.pair_blocks, (int)blockIdx.x - first);
 }
 
 // AvgPool2d(2) o conv3x3 = 0.25 * (transpose of the up-conv with the flipped, transposed filter): the same two kernels
@@ -3157,16 +3176,27 @@ static size_t s2_workspace(int B, int Clo, int Chi, int H, int W) {
   const int S = s2_splits(geo_tiles(g, B, H, W), (Clo + 15) / 16, (Chi + S2_CKW - 1) / S2_CKW);
   return ((size_t)S * Clo * Chi * 16 + (size_t)S * (Clo > Chi ? Clo : Chi)) * sizeof(float);
 }
-static int s2_wgrad(const float* hi, const float* lo, float* gw, float* gbias, float* ws, size_t ws_bytes, int B, int Clo, int Chi, int H,
-                    int W, int Cout, int Cin, int mode, int accumulate, hipStream_t st) {
+struct S2Plan { int S, tiles, lo_tiles, hi_chunks; };
+static S2Plan s2_plan(int B, int Clo, int Chi, int H, int W) {
+  const GeoId g = pick_geo(H, W);
+  S2Plan p;
+  p.tiles = geo_tiles(g, B, H, W);
+  p.lo_tiles = (Clo + 15) / 16;
+  p.hi_chunks = (Chi + S2_CKW - 1) / S2_CKW;
+  p.S = s2_splits(p.tiles, p.lo_tiles, p.hi_chunks);
+  return p;
+}
+// stage 1: per-workgroup partials of T (and of the bias gradient, want_bias) into ws
+static int s2_wgrad_stage1(const float* hi, const float* lo, float* ws, size_t ws_bytes, int B, int Clo, int Chi, int H, int W, int mode,
+                           int want_bias, hipStream_t st) {
   const GeoId g = pick_geo(H, W);
   if (!s2_geo(g) || check_shape(B, Clo, Chi, 2 * H, 2 * W, 3) != TG_OK) return TG_EUNSUPPORTED;
   if (ws_bytes < s2_workspace(B, Clo, Chi, H, W)) return TG_EWORKSPACE;
-  const int tiles = geo_tiles(g, B, H, W), lo_tiles = (Clo + 15) / 16, hi_chunks = (Chi + S2_CKW - 1) / S2_CKW;
-  const int S = s2_splits(tiles, lo_tiles, hi_chunks);
+  const S2Plan p = s2_plan(B, Clo, Chi, H, W);
+  const int tiles = p.tiles, S = p.S;
   Shape s{B, Chi, Clo, H, W};
-  dim3 grid(S, lo_tiles, hi_chunks);
-  float* bias_part = gbias ? ws + (size_t)S * Clo * Chi * 16 : nullptr;      // [S][Cout]: Cout == Clo (mode 0) or Chi (mode 1)
+  dim3 grid(S, p.lo_tiles, p.hi_chunks);
+  float* bias_part = want_bias ? ws + (size_t)S * Clo * Chi * 16 : nullptr;      // [S][Cout]: Cout == Clo (mode 0) or Chi (mode 1)
   const int vh = plane_vec_ok(hi, 2 * W), vl = plane_vec_ok(lo, W);
   if (vh && vl && dma_knobs().enable && dma_knobs().wgrad && (int64_t)B * (Chi > Clo ? Chi : Clo) * H * W * 16 < (1ll << 31)) {
     s.prio = dma_knobs().prio;
@@ -3174,9 +3204,60 @@ static int s2_wgrad(const float* hi, const float* lo, float* gw, float* gbias, f
   } else {
     TG_S2_DISPATCH(g, conv_wgrad_s2_kernel, hi, lo, ws, s, tiles, S, vh, vl, bias_part, mode);
   }
-  const int pair_blocks = (Clo * Chi + 3) / 4;
-  s2wgrad_reduce_fold_kernel<<<pair_blocks + (gbias ? (Cout + 3) / 4 : 0), 256, 0, st>>>(ws, gw, S, Clo, Chi, Cout, Cin, mode, accumulate,
-                                                                                       bias_part, gbias, pair_blocks);
+  return tg_launch_status();
+}
+static FoldItem s2_fold_item(const float* ws, float* gw, float* gbias, int B, int Clo, int Chi, int H, int W, int Cout, int Cin, int mode,
+                             int accumulate) {
+  const S2Plan p = s2_plan(B, Clo, Chi, H, W);
+  FoldItem it;
+  it.part = ws; it.gw = gw; it.gbias = gbias;
+  it.bias_part = gbias ? ws + (size_t)p.S * Clo * Chi * 16 : nullptr;
+  it.S = p.S; it.Clo = Clo; it.Chi = Chi; it.Cout = Cout; it.Cin = Cin; it.mode = mode; it.accumulate = accumulate;
+  it.pair_blocks = (Clo * Chi + 3) / 4;
+  return it;
+}
+static int s2_wgrad(const float* hi, const float* lo, float* gw, float* gbias, float* ws, size_t ws_bytes, int B, int Clo, int Chi, int H,
+                    int W, int Cout, int Cin, int mode, int accumulate, hipStream_t st) {
+  if (int rc = s2_wgrad_stage1(hi, lo, ws, ws_bytes, B, Clo, Chi, H, W, mode, gbias != nullptr, st)) return rc;
+  const FoldItem it = s2_fold_item(ws, gw, gbias, B, Clo, Chi, H, W, Cout, Cin, mode, accumulate);
+  s2wgrad_reduce_fold_kernel<<<it.pair_blocks + (gbias ? (Cout + 3) / 4 : 0), 256, 0, st>>>(it.part, gw, it.S, Clo, Chi, Cout, Cin, mode,
+                                                                                         accumulate, it.bias_part, gbias, it.pair_blocks);
+  return tg_launch_status();
+}
+
+int tg_poolconv3x3_wgrad_partials(const float* x, const float* gy, float* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
+                                  int H, int W, int want_bias, void* stream) {
+  TG_CHECK_PTR(x); TG_CHECK_PTR(gy); TG_CHECK_PTR(workspace);
+  return s2_wgrad_stage1(x, gy, workspace, workspace_bytes, B, Cout, Cin, H, W, 0, want_bias, tg_stream(stream));
+}
+int tg_upconv3x3_wgrad_partials(const float* a, const float* gy, float* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
+                                int H, int W, int want_bias, void* stream) {
+  TG_CHECK_PTR(a); TG_CHECK_PTR(gy); TG_CHECK_PTR(workspace);
+  return s2_wgrad_stage1(gy, a, workspace, workspace_bytes, B, Cin, Cout, H, W, 1, want_bias, tg_stream(stream));
+}
+int tg_s2_wgrad_reduce_batch(const tg_host_i64* items, int n_items, void* stream) {
+  if (n_items < 0) return TG_EINVAL;
+  if (n_items == 0) return TG_OK;
+  TG_CHECK_PTR(items);
+  hipStream_t st = tg_stream(stream);
+  for (int base = 0; base < n_items; base += SB_MAX_ITEMS) {
+    FoldBatch fb;
+    fb.n = n_items - base < SB_MAX_ITEMS ? n_items - base : SB_MAX_ITEMS;
+    int blocks = 0;
+    for (int i = 0; i < fb.n; ++i) {
+      const tg_host_i64* it = items + (size_t)(base + i) * TG_WGRAD_ITEM_FIELDS;
+      const int B = (int)it[3], Cin = (int)it[4], Cout = (int)it[5], H = (int)it[6], W = (int)it[7], mode = (int)it[8];
+      if (it[0] == 0 || it[1] == 0 || (mode != 0 && mode != 1)) return TG_EINVAL;
+      const int Clo = mode == 0 ? Cout : Cin, Chi = mode == 0 ? Cin : Cout;
+      if (!s2_geo(pick_geo(H, W)) || check_shape(B, Clo, Chi, 2 * H, 2 * W, 3) != TG_OK) return TG_EUNSUPPORTED;
+      fb.item[i] = s2_fold_item(reinterpret_cast<const float*>(it[0]), reinterpret_cast<float*>(it[1]), reinterpret_cast<float*>(it[2]),
+                                B, Clo, Chi, H, W, Cout, Cin, mode, (int)it[9]);
+      blocks += fb.item[i].pair_blocks + (fb.item[i].gbias ? (Cout + 3) / 4 : 0);
+      fb.block_end[i] = blocks;
+    }
+    for (int i = fb.n; i < SB_MAX_ITEMS; ++i) { fb.item[i] = fb.item[0]; fb.block_end[i] = blocks; }
+    s2wgrad_reduce_fold_batch_kernel<<<blocks, 256, 0, st>>>(fb);
+  }
   return tg_launch_status();
 }
 

@@ -546,6 +546,7 @@ class _DeferredWgrad:
     """State of ``deferred_wgrad()``: rows of the batch-reduce table + the partial-sum buffers they point at."""
     active = False
     items = []
+    s2_items = []       # the stride-2 forms' rows (tg_s2_wgrad_reduce_batch)
     keep = []
 
 
@@ -607,23 +608,28 @@ def flush_wgrad():
     if _WgradStream.used:
         torch.cuda.current_stream().wait_stream(_WgradStream.stream)
         _WgradStream.used = False
-        if not st.items:
+        if not st.items and not st.s2_items:
             st.keep = []
-    if st.items:
+    if st.items or st.s2_items:
         items, st.items = st.items, []
+        s2_items, st.s2_items = st.s2_items, []
         try:
             # A weight that collected several contributions in this pass (the discriminator sees the real and the
             # fake batch) must not be updated by two workgroups of one launch: contribution k of every weight goes
             # into launch k, in recording order (= the order the per-layer calls would have accumulated in).
-            rounds, seen = [], {}
-            for row in items:
-                k = seen.get(row[1], 0)
-                seen[row[1]] = k + 1
-                if k == len(rounds):
-                    rounds.append([])
-                rounds[k].append(row)
-            for rows in rounds:
+            def in_rounds(table):
+                rounds, seen = [], {}
+                for row in table:
+                    k = seen.get(row[1], 0)
+                    seen[row[1]] = k + 1
+                    if k == len(rounds):
+                        rounds.append([])
+                    rounds[k].append(row)
+                return rounds
+            for rows in in_rounds(items):
                 K().conv2d_wgrad_reduce_batch(torch.tensor(rows, dtype=torch.int64), len(rows))
+            for rows in in_rounds(s2_items):          # (a layer is one form or the other: the two tables share no gradient)
+                K().s2_wgrad_reduce_batch(torch.tensor(rows, dtype=torch.int64), len(rows))
         finally:
             st.keep = []
 
@@ -642,6 +648,26 @@ def _conv_wgrad_into(x, gy, gw, gbias, ks, accumulate):
         return
     ws = _ws(x, nbytes)
     K().conv2d_wgrad(x, gy, gw, gbias, ws, ws.numel() * 4, B, Cin, Cout, H, W, ks, accumulate)
+
+
+def _s2_wgrad_into(mode, lo_or_x, gy, gw, gbias, B, Cin, Cout, H, W):
+    """Accumulate the weight (and bias) gradient of a stride-2 layer into ``gw`` (``gbias``): mode 0 the pooled conv (x high
+    resolution, gy low), mode 1 the up-conv (a low resolution, gy high); (H, W) the LOW-resolution plane.  Inside
+    ``deferred_wgrad()`` only stage 1 runs now; the sums, the fold onto the 3x3 taps and the bias gradients of all such layers of
+    the pass are finished by one launch when the context exits."""
+    name = 'poolconv3x3' if mode == 0 else 'upconv3x3'
+    nbytes = getattr(K(), name + '_wgrad_workspace')(B, Cin, Cout, H, W)
+    if _DeferredWgrad.active:
+        ws = gy.new_empty(nbytes // 4 + 4)               # its own buffer: must survive until the batch reduce
+        with _beside_backward(lo_or_x, gy, ws):
+            getattr(K(), name + '_wgrad_partials')(lo_or_x, gy, ws, ws.numel() * 4, B, Cin, Cout, H, W, int(gbias is not None))
+        _DeferredWgrad.s2_items.append([ws.data_ptr(), gw.data_ptr(), gbias.data_ptr() if gbias is not None else 0,
+                                        B, Cin, Cout, H, W, mode, 1])
+        _DeferredWgrad.keep.append((ws, gw, gbias))
+        return
+    ws = _ws(gy, nbytes)
+    with _beside_backward(lo_or_x, gy, ws):
+        getattr(K(), name + '_wgrad')(lo_or_x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, 1, gbias)
 
 
 class _ConvWgrad(Function):
@@ -890,8 +916,7 @@ class _UpConv3x3(Function):
                     gb = torch.empty_like(bias) if with_b else None
                     K().upconv3x3_wgrad(a, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, gb)
                 else:
-                    with _beside_backward(a, gy, ws):
-                        K().upconv3x3_wgrad(a, gy, sink_w, ws, ws.numel() * 4, B, Cin, Cout, H, W, 1, sink_b if with_b else None)
+                    _s2_wgrad_into(1, a, gy, sink_w, sink_b if with_b else None, B, Cin, Cout, H, W)
                 need_b = need_b and not with_b
             elif sink_w is not None:
                 _conv_wgrad_into(upsample_nearest2x(a), gy, sink_w, None, 3, accumulate=1)
@@ -1065,9 +1090,7 @@ class _PoolConv(Function):
                     gb = torch.empty_like(bias) if with_b else None
                     K().poolconv3x3_wgrad(x, gy, gw, ws, ws.numel() * 4, B, Cin, Cout, H2 // 2, W2 // 2, 0, gb)
                 else:
-                    with _beside_backward(x, gy, ws):
-                        K().poolconv3x3_wgrad(x, gy, sink_w, ws, ws.numel() * 4, B, Cin, Cout, H2 // 2, W2 // 2, 1,
-                                              sink_b if with_b else None)
+                    _s2_wgrad_into(0, x, gy, sink_w, sink_b if with_b else None, B, Cin, Cout, H2 // 2, W2 // 2)
                 need_b = need_b and not with_b
         if need_b:                                                   # bias gradient at the LOW resolution
             sink_b = _grad_sink(bias)
@@ -1108,13 +1131,12 @@ class _PoolConvT(Function):
                 B, Cout, H, W = gy.shape
                 Cin = w.shape[1]
                 sink = _grad_sink(w)
-                ws = _ws(v, K().poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
                 if sink is None:
+                    ws = _ws(v, K().poolconv3x3_wgrad_workspace(B, Cin, Cout, H, W))
                     a_w = torch.empty_like(w)
                     K().poolconv3x3_wgrad(v, gy, a_w, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, None)
                 else:
-                    with _beside_backward(v, gy, ws):
-                        K().poolconv3x3_wgrad(v, gy, sink, ws, ws.numel() * 4, B, Cin, Cout, H, W, 1, None)
+                    _s2_wgrad_into(0, v, gy, sink, None, B, Cin, Cout, H, W)
         return a_gy, a_w
 
 

@@ -109,7 +109,7 @@ class Emulator:
         return self.upconv3x3_fwd(gy, wp, None, None, gx, B, Cout, Cin, H, W)
 
     def poolconv3x3_wgrad_workspace(self, B, Cin, Cout, H, W):
-        return 16
+        return (Cout * Cin * 9 + Cout) * 4
 
     def poolconv3x3_wgrad(self, x, gy, gw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, gbias=None):
         g_hi = (_v(gy, B, Cout, H, W) * 0.25).repeat_interleave(2, 2).repeat_interleave(2, 3)
@@ -121,7 +121,7 @@ class Emulator:
         return 0
 
     def upconv3x3_wgrad_workspace(self, B, Cin, Cout, H, W):
-        return 16
+        return (Cout * Cin * 9 + Cout) * 4
 
     def upconv3x3_wgrad(self, a, gy, gw, ws, ws_bytes, B, Cin, Cout, H, W, accumulate, gbias=None):
         a_hi = _v(a, B, Cin, H, W).repeat_interleave(2, 2).repeat_interleave(2, 3)
@@ -187,6 +187,43 @@ class Emulator:
             if gbias:
                 dstb = at(gbias, Cout)
                 src = at(part + 4 * E, Cout)
+                dstb.copy_(dstb + src if accumulate else src)
+        return 0
+
+    # stride-2 weight gradients in two steps: stage 1 leaves the finished gradient (and bias gradient) in the workspace
+    def poolconv3x3_wgrad_partials(self, x, gy, ws, ws_bytes, B, Cin, Cout, H, W, want_bias):
+        E = Cout * Cin * 9
+        assert ws_bytes >= (E + Cout) * 4
+        gw, gb = torch.zeros(Cout, Cin, 3, 3), torch.zeros(Cout)
+        self.poolconv3x3_wgrad(x, gy, gw, None, 0, B, Cin, Cout, H, W, 0, gb if want_bias else None)
+        ws[:E].copy_(gw.reshape(-1))
+        ws[E:E + Cout].copy_(gb)
+        return 0
+
+    def upconv3x3_wgrad_partials(self, a, gy, ws, ws_bytes, B, Cin, Cout, H, W, want_bias):
+        E = Cout * Cin * 9
+        assert ws_bytes >= (E + Cout) * 4
+        gw, gb = torch.zeros(Cout, Cin, 3, 3), torch.zeros(Cout)
+        self.upconv3x3_wgrad(a, gy, gw, None, 0, B, Cin, Cout, H, W, 0, gb if want_bias else None)
+        ws[:E].copy_(gw.reshape(-1))
+        ws[E:E + Cout].copy_(gb)
+        return 0
+
+    def s2_wgrad_reduce_batch(self, items, n_items):
+        import ctypes
+        import numpy as np
+
+        def at(addr, n):
+            return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(addr)))
+
+        assert items.dtype == torch.int64 and tuple(items.shape) == (n_items, 10)
+        for part, gw, gbias, B, Cin, Cout, H, W, mode, accumulate in items.tolist():
+            assert mode in (0, 1)
+            E = Cout * Cin * 9
+            dst = at(gw, E)
+            dst.copy_(dst + at(part, E) if accumulate else at(part, E))
+            if gbias:
+                dstb, src = at(gbias, Cout), at(part + 4 * E, Cout)
                 dstb.copy_(dstb + src if accumulate else src)
         return 0
 

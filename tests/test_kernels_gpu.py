@@ -267,6 +267,39 @@ def test_stride2_weight_gradients(K, shape):
     run_both(K, 'upconv3x3_wgrad', [a, gyh, w0.clone(), ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, None], [2], tol=1e-4, scratch=[3])
 
 
+@pytest.mark.parametrize('shape', [(16, 16, 16, 64, 64), (32, 32, 24, 16, 16), (10, 20, 18, 70, 50), (64, 128, 128, 8, 8)])
+def test_stride2_weight_gradients_in_two_steps_are_bit_identical(K, shape):
+    """tg_*_wgrad_partials + ONE tg_s2_wgrad_reduce_batch for several layers == the one-call forms, bit for bit, incl. the bias
+    gradients and accumulation into an existing gradient."""
+    B, Cin, Cout, H, W = shape
+    x, gy = rnd(B, Cin, 2 * H, 2 * W).cuda(), rnd(B, Cout, H, W, seed=3).cuda()
+    a, gyh = rnd(B, Cin, H, W, seed=4).cuda(), rnd(B, Cout, 2 * H, 2 * W, seed=5).cuda()
+    w0, b0 = rnd(Cout, Cin, 3, 3, seed=9).cuda(), rnd(Cout, seed=10).cuda()
+    want = []
+    for name, lo, hi in (('poolconv3x3', x, gy), ('upconv3x3', a, gyh)):
+        ws = torch.zeros(getattr(K, name + '_wgrad_workspace')(B, Cin, Cout, H, W) // 4 + 4, device='cuda')
+        gw, gb = w0.clone(), b0.clone()
+        getattr(K, name + '_wgrad')(lo, hi, gw, ws, ws.numel() * 4, B, Cin, Cout, H, W, 1, gb)
+        gw2 = w0.clone()
+        getattr(K, name + '_wgrad')(lo, hi, gw2, ws, ws.numel() * 4, B, Cin, Cout, H, W, 0, None)
+        want.append((gw, gb, gw2))
+    rows, got, keep = [], [], []
+    for mode, (name, lo, hi) in enumerate((('poolconv3x3', x, gy), ('upconv3x3', a, gyh))):
+        for with_bias, acc in ((1, 1), (0, 0)):
+            ws = torch.zeros(getattr(K, name + '_wgrad_workspace')(B, Cin, Cout, H, W) // 4 + 4, device='cuda')
+            getattr(K, name + '_wgrad_partials')(lo, hi, ws, ws.numel() * 4, B, Cin, Cout, H, W, with_bias)
+            gw, gb = w0.clone(), b0.clone()
+            rows.append([ws.data_ptr(), gw.data_ptr(), gb.data_ptr() if with_bias else 0, B, Cin, Cout, H, W, mode, acc])
+            got.append((gw, gb))
+            keep.append(ws)
+    K.s2_wgrad_reduce_batch(torch.tensor(rows, dtype=torch.int64), len(rows))
+    torch.cuda.synchronize()
+    for mode in (0, 1):
+        gw, gb, gw2 = want[mode]
+        assert torch.equal(got[2 * mode][0], gw) and torch.equal(got[2 * mode][1], gb)
+        assert torch.equal(got[2 * mode + 1][0], gw2) and torch.equal(got[2 * mode + 1][1], b0)
+
+
 @pytest.mark.parametrize('op', ['pool_conv', 'up_conv'])
 def test_stride2_functions_under_autograd(K, op):
     """The Functions built on the stride-2 kernels, on the GPU, against plain torch on the CPU: values, first-order
