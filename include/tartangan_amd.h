@@ -146,6 +146,12 @@ int tg_poolconv3x3_weights_batch(const tg_host_i64* items /*host*/, int n_items,
  * finishes the bias gradients of all recorded layers.  Items as for tg_conv2d_wgrad_reduce_batch with [8] = 0 (pooled conv: stage 1
  * by tg_poolconv3x3_wgrad_partials) or 1 (up-conv: tg_upconv3x3_wgrad_partials) in the place of ks; (B, ., H, W) the LOW-resolution
  * plane; [2] gbias nonzero needs want_bias != 0 in stage 1.  Bit-identical to the one-call forms.                               */
+/* The discriminator's from-RGB 1x1 convolution composed into the 3x3 convolution that follows it (discriminator.py:11-22 + :60-61,
+ * nothing in between): wc [Cout][Cimg + 1][3][3] = sum_m [w1 | b1][m][c] * w3[co][m][tap] (the from-RGB bias on an all-ones input channel),
+ * and its backward (gw1 [C][Cimg], gb1 [C], gw3 [Cout][C][3][3]; accumulate: += into all three).  One launch each.          */
+int tg_rgb_compose_fwd(const float* w1, const float* b1, const float* w3, float* wc, int Cout, int C, int Cimg, void* stream);
+int tg_rgb_compose_bwd(const float* gwc, const float* w1, const float* b1, const float* w3, float* gw1, float* gb1, float* gw3, int Cout,
+                       int C, int Cimg, int accumulate, void* stream);
 int tg_poolconv3x3_wgrad_partials(const float* x, const float* gy, float* workspace, size_t workspace_bytes, int B, int Cin, int Cout,
                                   int H, int W, int want_bias, void* stream);
 int tg_upconv3x3_wgrad_partials(const float* a, const float* gy, float* workspace, size_t workspace_bytes, int B, int Cin, int Cout,

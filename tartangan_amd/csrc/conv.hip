@@ -2715,6 +2715,47 @@ __global__ void __launch_bounds__(256) poolconv_weights_batch_kernel(FormBatch f
   poolconv_weights_one(it.w, it.w4, it.wp, it.Cout, it.Cin, ((int)blockIdx.x - first) * 256 + threadIdx.x);
 }
 
+// =========================================================================== from-RGB 1x1 composed into the first 3x3
+// wc[co][c][tap] = sum_m w1c[m][c] * w3[co][m][tap],  w1c = [w1 | b1] (C x (Cimg + 1): the from-RGB bias rides on an all-ones input
+// channel).  One thread per output; the backward (one launch): gw3[co][m][tap] = sum_c gwc[co][c][tap] w1c[m][c],
+// gw1c[m][c] = sum_{co, tap} gwc[co][c][tap] w3[co][m][tap] -- a few thousand multiply-adds that used to be a cat, a broadcast copy,
+// a batched GEMM and, backwards, two GEMMs, a sum and three accumulations.
+__device__ __forceinline__ float rgb_w1c(const float* __restrict__ w1, const float* __restrict__ b1, int m, int c, int Cimg) {
+  return c < Cimg ? w1[m * Cimg + c] : b1[m];
+}
+__global__ void __launch_bounds__(256) rgb_compose_fwd_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ w3, float* __restrict__ wc, int Cout, int C,
+                                                              int Cimg) {
+  const int n = Cout * (Cimg + 1) * 9;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int tap = e % 9, c = (e / 9) % (Cimg + 1), co = e / (9 * (Cimg + 1));
+    float acc = 0.f;
+    for (int m = 0; m < C; ++m) acc = fmaf(rgb_w1c(w1, b1, m, c, Cimg), w3[(co * C + m) * 9 + tap], acc);
+    wc[e] = acc;
+  }
+}
+__global__ void __launch_bounds__(256) rgb_compose_bwd_kernel(const float* __restrict__ gwc, const float* __restrict__ w1,
+                                                              const float* __restrict__ b1, const float* __restrict__ w3,
+                                                              float* __restrict__ gw1, float* __restrict__ gb1, float* __restrict__ gw3,
+                                                              int Cout, int C, int Cimg, int accumulate) {
+  const int n3 = Cout * C * 9, n1 = C * (Cimg + 1);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n3 + n1; e += gridDim.x * 256) {
+    if (e < n3) {
+      const int tap = e % 9, m = (e / 9) % C, co = e / (9 * C);
+      float acc = 0.f;
+      for (int c = 0; c <= Cimg; ++c) acc = fmaf(gwc[(co * (Cimg + 1) + c) * 9 + tap], rgb_w1c(w1, b1, m, c, Cimg), acc);
+      gw3[e] = accumulate ? gw3[e] + acc : acc;
+    } else {
+      const int k = e - n3, c = k % (Cimg + 1), m = k / (Cimg + 1);
+      float acc = 0.f;
+      for (int co = 0; co < Cout; ++co)
+        for (int tap = 0; tap < 9; ++tap) acc = fmaf(gwc[(co * (Cimg + 1) + c) * 9 + tap], w3[(co * C + m) * 9 + tap], acc);
+      float* o = c < Cimg ? gw1 + m * Cimg + c : gb1 + m;
+      *o = accumulate ? *o + acc : acc;
+    }
+  }
+}
+
 // =========================================================================== host dispatch
 enum GeoId { GEO_4, GEO_8, GEO_16, GEO_X };
 static inline GeoId pick_geo(int H, int W) {
@@ -3278,6 +3319,21 @@ int tg_upconv3x3_wgrad(const float* a, const float* gy, float* gw, float* worksp
                        int Cout, int H, int W, int accumulate, float* gbias, void* stream) {
   TG_CHECK_PTR(a); TG_CHECK_PTR(gy); TG_CHECK_PTR(gw); TG_CHECK_PTR(workspace);
   return s2_wgrad(gy, a, gw, gbias, workspace, workspace_bytes, B, Cin, Cout, H, W, Cout, Cin, 1, accumulate, tg_stream(stream));
+}
+
+int tg_rgb_compose_fwd(const float* w1, const float* b1, const float* w3, float* wc, int Cout, int C, int Cimg, void* stream) {
+  TG_CHECK_PTR(w1); TG_CHECK_PTR(b1); TG_CHECK_PTR(w3); TG_CHECK_PTR(wc); TG_CHECK_POS(Cout); TG_CHECK_POS(C); TG_CHECK_POS(Cimg);
+  const int n = Cout * (Cimg + 1) * 9;
+  rgb_compose_fwd_kernel<<<(n + 255) / 256, 256, 0, tg_stream(stream)>>>(w1, b1, w3, wc, Cout, C, Cimg);
+  return tg_launch_status();
+}
+int tg_rgb_compose_bwd(const float* gwc, const float* w1, const float* b1, const float* w3, float* gw1, float* gb1, float* gw3, int Cout,
+                       int C, int Cimg, int accumulate, void* stream) {
+  TG_CHECK_PTR(gwc); TG_CHECK_PTR(w1); TG_CHECK_PTR(b1); TG_CHECK_PTR(w3); TG_CHECK_PTR(gw1); TG_CHECK_PTR(gb1); TG_CHECK_PTR(gw3);
+  TG_CHECK_POS(Cout); TG_CHECK_POS(C); TG_CHECK_POS(Cimg);
+  const int n = Cout * C * 9 + C * (Cimg + 1);
+  rgb_compose_bwd_kernel<<<(n + 255) / 256, 256, 0, tg_stream(stream)>>>(gwc, w1, b1, w3, gw1, gb1, gw3, Cout, C, Cimg, accumulate);
+  return tg_launch_status();
 }
 
 int tg_poolconv3x3_weights_batch(const tg_host_i64* items, int n_items, void* stream) {

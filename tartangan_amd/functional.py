@@ -734,6 +734,45 @@ def conv2d(x, weight, bias=None, residual=None, residual_up=False):
 PAIR_SPECS[_ConvFwd] = ('b--b-', 'h--', 'b')
 
 
+# =========================================================================== from-RGB 1x1 composed into the first 3x3
+class _ComposeRGB(Function):
+    """wc[co][c][tap] = sum_m [w1 | b1][m][c] * w3[co][m][tap]: the filter of conv3x3(conv1x1(img) + b1) as ONE convolution over
+    [img, 1] (discriminator.py:11-22 + :60-61).  Parameters in, a derived filter out: its backward is only ever a plain
+    first-order one (the R1 penalty differentiates w.r.t. the images, never w.r.t. a filter with create_graph)."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, w3):
+        w1, b1, w3 = w1.contiguous(), b1.contiguous(), w3.contiguous()
+        Cout, C = w3.shape[:2]
+        Cimg = w1.shape[1]
+        wc = w3.new_empty(Cout, Cimg + 1, 3, 3)
+        K().rgb_compose_fwd(w1, b1, w3, wc, Cout, C, Cimg)
+        ctx.save_for_backward(w1, b1, w3)
+        return wc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gwc):
+        w1, b1, w3 = ctx.saved_tensors
+        if not _param_grads_wanted() or not any(ctx.needs_input_grad):
+            return None, None, None
+        Cout, C = w3.shape[:2]
+        Cimg = w1.shape[1]
+        sinks = [_grad_sink(p) for p in (w1, b1, w3)]
+        if all(ctx.needs_input_grad) and all(sk is not None for sk in sinks):
+            K().rgb_compose_bwd(gwc.contiguous(), w1, b1, w3, sinks[0], sinks[1], sinks[2], Cout, C, Cimg, 1)
+            return None, None, None
+        g1, gb, g3 = torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w3)
+        K().rgb_compose_bwd(gwc.contiguous(), w1, b1, w3, g1, gb, g3, Cout, C, Cimg, 0)
+        need = ctx.needs_input_grad
+        return (g1 if need[0] else None), (gb if need[1] else None), (g3 if need[2] else None)
+
+
+def compose_rgb_filter(w1, b1, w3):
+    """-> (Cout, Cimg + 1, 3, 3): conv3x3(conv1x1(img, w1) + b1, w3) == conv3x3([img, 1], result) with zero padding."""
+    return _ComposeRGB.apply(w1, b1, w3)
+
+
 # =========================================================================== theta | phi | g of SelfAttention2d
 def _adjacent(ts):
     """One (rows, cols) view over tensors that lie back to back in one storage (the parameters of a network, and their

@@ -83,8 +83,7 @@ class ResidualDiscriminatorBlock(nn.Module):
         rgb_conv, conv1 = rgb.convs[0], self.convs[0]
         C, Cimg = rgb_conv.weight.shape[:2]
         Cout = conv1.weight.shape[0]
-        w1 = torch.cat([rgb_conv.weight.view(C, Cimg), rgb_conv.bias.view(C, 1)], 1)                  # (C, Cimg + 1)
-        wc = TF.matmul(w1.unsqueeze(0).expand(Cout, C, Cimg + 1), conv1.weight.view(Cout, C, 9), transA=True)
+        wc = TF.compose_rgb_filter(rgb_conv.weight, rgb_conv.bias, conv1.weight)                      # one launch (and one backwards)
         img_a = img_b = img
         if img.requires_grad and torch.is_grad_enabled():
             img_a, img_b = TF.fork(img, 2)         # two consumers (R1 differentiates w.r.t. the images): one fan-in kernel

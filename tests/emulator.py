@@ -227,6 +227,22 @@ class Emulator:
                 dstb.copy_(dstb + src if accumulate else src)
         return 0
 
+    def rgb_compose_fwd(self, w1, b1, w3, wc, Cout, C, Cimg):
+        w1c = torch.cat([_v(w1, C, Cimg), _v(b1, C, 1)], 1)
+        _v(wc, Cout, Cimg + 1, 9).copy_(torch.einsum('mc,omt->oct', w1c, _v(w3, Cout, C, 9)))
+        return 0
+
+    def rgb_compose_bwd(self, gwc, w1, b1, w3, gw1, gb1, gw3, Cout, C, Cimg, accumulate):
+        w1c = torch.cat([_v(w1, C, Cimg), _v(b1, C, 1)], 1)
+        g = _v(gwc, Cout, Cimg + 1, 9)
+        r3 = torch.einsum('oct,mc->omt', g, w1c).reshape(gw3.shape)
+        r1c = torch.einsum('oct,omt->mc', g, _v(w3, Cout, C, 9))
+        r1, rb = r1c[:, :Cimg].reshape(gw1.shape), r1c[:, Cimg].reshape(gb1.shape)
+        gw3.copy_(gw3 + r3 if accumulate else r3)
+        gw1.copy_(gw1 + r1 if accumulate else r1)
+        gb1.copy_(gb1 + rb if accumulate else rb)
+        return 0
+
     def poolconv3x3_weights_batch(self, items, n_items):
         import ctypes
         import numpy as np

@@ -650,3 +650,33 @@ def test_filter_forms_scope_for_a_module_derives_its_known_filters_in_one_launch
     with TF.filter_forms(owner):
         pass
     assert batch[-1] == 2
+
+
+def test_composed_from_rgb_filter_and_its_gradients():
+    """conv3x3(conv1x1(img) + b1) == conv3x3([img, 1], compose_rgb_filter(...)) with zero padding, and the three parameter gradients
+    equal autograd's through the two-layer formulation -- returned as tensors, or accumulated straight into ``.grad``."""
+    torch.manual_seed(0)
+    C, Cimg, Cout = 6, 3, 5
+    w1 = torch.nn.Parameter(torch.randn(C, Cimg, 1, 1) * 0.5)
+    b1 = torch.nn.Parameter(torch.randn(C) * 0.5)
+    w3 = torch.nn.Parameter(torch.randn(Cout, C, 3, 3) * 0.3)
+    img = torch.randn(2, Cimg, 8, 8)
+    F = torch.nn.functional
+    ref = F.conv2d(F.conv2d(img, w1, b1), w3, None, padding=1)
+    wc = TF.compose_rgb_filter(w1, b1, w3)
+    got = F.conv2d(torch.cat([img, torch.ones(2, 1, 8, 8)], 1), wc, None, padding=1)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5)
+    cot = torch.randn_like(ref)
+    want = torch.autograd.grad((ref * cot).sum(), [w1, b1, w3])
+    have = torch.autograd.grad((got * cot).sum(), [w1, b1, w3])
+    for a, b in zip(have, want):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5)
+    # accumulated in place inside the trainers' backward context
+    for p in (w1, b1, w3):
+        p.grad = torch.ones_like(p)
+    wc = TF.compose_rgb_filter(w1, b1, w3)
+    loss = (F.conv2d(torch.cat([img, torch.ones(2, 1, 8, 8)], 1), wc, None, padding=1) * cot).sum()
+    with TF.grads_into_buckets():
+        loss.backward()
+    for p, b in zip((w1, b1, w3), want):
+        assert torch.allclose(p.grad, 1 + b, rtol=1e-4, atol=1e-5)

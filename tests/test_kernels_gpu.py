@@ -719,6 +719,17 @@ def test_fused_attention_unsupported_dims(K):
                    torch.zeros(1, 16).cuda(), 1, 3, 12, 16, 4)
 
 
+@pytest.mark.parametrize('dims', [(16, 16, 3), (32, 16, 3), (5, 7, 2)])
+def test_composed_from_rgb_filter(K, dims):
+    Cout, C, Cimg = dims
+    w1, b1, w3 = rnd(C, Cimg), rnd(C, seed=1), rnd(Cout, C, 3, 3, seed=2)
+    run_both(K, 'rgb_compose_fwd', [w1, b1, w3, torch.zeros(Cout, Cimg + 1, 3, 3), Cout, C, Cimg], [3], tol=2e-6)
+    gwc = rnd(Cout, Cimg + 1, 3, 3, seed=3)
+    for acc in (0, 1):
+        run_both(K, 'rgb_compose_bwd', [gwc, w1, b1, w3, rnd(C, Cimg, seed=4), rnd(C, seed=5), rnd(Cout, C, 3, 3, seed=6), Cout, C, Cimg, acc],
+                 [4, 5, 6], tol=5e-6)
+
+
 def test_iqn_and_losses(K):
     Q, B = 8, 24
     taus = torch.rand(Q * B, 1)
