@@ -154,15 +154,25 @@ int launch_unary(const float* x, float* out, int64_t n, void* stream, Op op) {
 struct RedDot { __device__ double term(const float* a, const float* b, int64_t i) const { return (double)a[i] * (double)b[i]; } };
 struct RedSumSq { __device__ double term(const float* a, const float*, int64_t i) const { return (double)a[i] * (double)a[i]; } };
 
+// A reduction that fits one block (<= 1024 elements: the logits of a batch, the quantile rows of an IQN head) is finished by that
+// block -- the same (float)(alpha * sum) the second stage would form from its single partial -- instead of by a second launch.
+struct Finish {
+  float* out; double alpha; int accumulate;           // out == nullptr: several blocks, the partial goes to stage 2
+  __device__ void put(double* __restrict__ partial, double acc) const {
+    if (out) *out = (float)(alpha * acc) + (accumulate ? *out : 0.f);
+    else partial[blockIdx.x] = acc;
+  }
+};
+
 template <class R>
 __global__ void __launch_bounds__(RED_BLOCK) reduce_stage1(const float* __restrict__ a, const float* __restrict__ b,
-                                                           double* __restrict__ partial, int64_t n, R r) {
+                                                           double* __restrict__ partial, int64_t n, R r, Finish fin) {
   __shared__ double scratch[32];
   double acc = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)RED_BLOCK + threadIdx.x; i < n; i += gridDim.x * (int64_t)RED_BLOCK)
     acc += r.term(a, b, i);
   acc = block_sum_d(acc, scratch);
-  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+  if (threadIdx.x == 0) fin.put(partial, acc);
 }
 
 __global__ void __launch_bounds__(RED_BLOCK) reduce_stage2(const double* __restrict__ partial, int nparts, double alpha,
@@ -187,15 +197,15 @@ int launch_reduce(const float* a, const float* b, double alpha, float* out, floa
   if (n <= 0) return TG_EINVAL;
   double* partial = reinterpret_cast<double*>(ws);
   const int g = red_grid(n);
-  reduce_stage1<R><<<g, RED_BLOCK, 0, tg_stream(stream)>>>(a, b, partial, n, r);
-  reduce_stage2<<<1, RED_BLOCK, 0, tg_stream(stream)>>>(partial, g, alpha, out, accumulate);
+  reduce_stage1<R><<<g, RED_BLOCK, 0, tg_stream(stream)>>>(a, b, partial, n, r, Finish{g == 1 ? out : nullptr, alpha, accumulate});
+  if (g > 1) reduce_stage2<<<1, RED_BLOCK, 0, tg_stream(stream)>>>(partial, g, alpha, out, accumulate);
   return tg_launch_status();
 }
 
 // ------------------------------------------------------------------ losses
 // BCE-with-logits, mean reduction: loss_i = (1-t) x + max(-x,0) + log1p(exp(-|x|))
 __global__ void __launch_bounds__(RED_BLOCK) bce_stage1(const float* __restrict__ x, const float* __restrict__ t,
-                                                        float* __restrict__ dlogits, double* __restrict__ partial, int n) {
+                                                        float* __restrict__ dlogits, double* __restrict__ partial, int n, Finish fin) {
   __shared__ double scratch[32];
   double acc = 0.0;
   const float inv_n = 1.f / (float)n;
@@ -207,13 +217,13 @@ __global__ void __launch_bounds__(RED_BLOCK) bce_stage1(const float* __restrict_
     dlogits[i] = (sig - ti) * inv_n;
   }
   acc = block_sum_d(acc, scratch);
-  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+  if (threadIdx.x == 0) fin.put(partial, acc);
 }
 
 // IQN quantile Huber loss (models/iqn.py:111-130), out_dims = 1, row = q*B + b
 __global__ void __launch_bounds__(RED_BLOCK) iqn_loss_stage1(const float* __restrict__ preds, const float* __restrict__ target,
                                                              const float* __restrict__ taus, float k, float* __restrict__ dpreds,
-                                                             double* __restrict__ partial, int Q, int B, int G) {
+                                                             double* __restrict__ partial, int Q, int B, int G, Finish fin) {
   // G independent evaluations back to back (rows g*Q*B + q*B + b, targets g*B + b): the sum of their losses
   __shared__ double scratch[32];
   double acc = 0.0;
@@ -231,7 +241,7 @@ __global__ void __launch_bounds__(RED_BLOCK) iqn_loss_stage1(const float* __rest
     dpreds[i] = -w * dh * inv_b;
   }
   acc = block_sum_d(acc, scratch);
-  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+  if (threadIdx.x == 0) fin.put(partial, acc);
 }
 
 __global__ void __launch_bounds__(EW_BLOCK) iqn_cos_embed_kernel(const float* __restrict__ taus, const float* __restrict__ range,
@@ -334,8 +344,8 @@ int tg_bce_logits(const float* logits, const float* targets, float* loss, float*
   TG_CHECK_POS(n);
   double* partial = reinterpret_cast<double*>(workspace);
   const int g = red_grid(n);
-  bce_stage1<<<g, RED_BLOCK, 0, tg_stream(stream)>>>(logits, targets, dlogits, partial, n);
-  reduce_stage2<<<1, RED_BLOCK, 0, tg_stream(stream)>>>(partial, g, 1.0 / (double)n, loss);
+  bce_stage1<<<g, RED_BLOCK, 0, tg_stream(stream)>>>(logits, targets, dlogits, partial, n, Finish{g == 1 ? loss : nullptr, 1.0 / (double)n, 0});
+  if (g > 1) reduce_stage2<<<1, RED_BLOCK, 0, tg_stream(stream)>>>(partial, g, 1.0 / (double)n, loss);
   return tg_launch_status();
 }
 
@@ -345,8 +355,9 @@ int tg_iqn_loss_groups(const float* preds, const float* target, const float* tau
   TG_CHECK_POS(Q); TG_CHECK_POS(B); TG_CHECK_POS(groups);
   double* partial = reinterpret_cast<double*>(workspace);
   const int g = red_grid((int64_t)Q * B * groups);
-  iqn_loss_stage1<<<g, RED_BLOCK, 0, tg_stream(stream)>>>(preds, target, taus, k, dpreds, partial, Q, B, groups);
-  reduce_stage2<<<1, RED_BLOCK, 0, tg_stream(stream)>>>(partial, g, 1.0 / (double)B, loss);
+  iqn_loss_stage1<<<g, RED_BLOCK, 0, tg_stream(stream)>>>(preds, target, taus, k, dpreds, partial, Q, B, groups,
+                                                          Finish{g == 1 ? loss : nullptr, 1.0 / (double)B, 0});
+  if (g > 1) reduce_stage2<<<1, RED_BLOCK, 0, tg_stream(stream)>>>(partial, g, 1.0 / (double)B, loss);
   return tg_launch_status();
 }
 int tg_iqn_loss(const float* preds, const float* target, const float* taus, float k, float* loss, float* dpreds,

@@ -747,6 +747,9 @@ def test_iqn_and_losses(K):
     run_both(K, 'iqn_loss_groups', [preds2, target2, taus2, 1.0, torch.zeros(()), torch.zeros(2 * Q * B, 1), ws, Q, B, 2], [4, 5], tol=2e-6)
     logits, t = rnd(48, 1) * 4, (torch.arange(48) % 2).float().view(48, 1)
     run_both(K, 'bce_logits', [logits, t, torch.zeros(()), torch.zeros(48, 1), ws, 48], [2, 3], tol=2e-6)
+    # more than one block of partials (the one-block case above is finished by its own kernel)
+    logits, t = rnd(5000, 1, seed=3) * 4, (torch.arange(5000) % 2).float().view(5000, 1)
+    run_both(K, 'bce_logits', [logits, t, torch.zeros(()), torch.zeros(5000, 1), ws, 5000], [2, 3], tol=2e-6)
 
 
 def test_adam_and_ema(K):
