@@ -339,6 +339,22 @@ class CNNTrainer(Trainer):
             iqn.tau_source = lambda rows, q: self._draw('tau', rows, q)
 
     def _capture(self, imgs):
+        """Capture the step's graphs.  The cyclic garbage collector is held off for the duration: a collection that happens to
+        run INSIDE a capture and frees something whose destructor talks to the driver (an earlier trainer's CUDAGraph or its memory
+        pool -- trainers are cyclic: components, RNG hooks) is an illegal call under stream capture and aborts the process.
+        ``torch.cuda.graph`` collects before it starts capturing for the same reason; that does not cover garbage that becomes
+        collectable, or a generation threshold that trips, while the capture is running."""
+        import gc
+        was_enabled = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            self._capture_graphs(imgs)
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _capture_graphs(self, imgs):
         feed = self.rng_feed
         feed.cursor = 0
         self._static_imgs = imgs.clone()

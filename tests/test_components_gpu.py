@@ -131,3 +131,27 @@ def test_checkpoint_written_on_the_device_loads_on_the_cpu_emulator(tmp_path):
     assert all(v.device.type == 'cpu' for v in g.state_dict().values())
     for (k, v), (k2, w) in zip(g.state_dict().items(), tr.g.state_dict().items()):
         assert k == k2 and torch.equal(v, w.cpu()), k
+
+
+def test_garbage_collection_during_graph_capture_is_harmless(tmp_path):
+    """An earlier graphed trainer that is only cyclic garbage by the time the next trainer captures its step (components and RNG
+    hooks make trainers cyclic): with the collector's thresholds at 1 a collection would run inside the capture and free the old
+    trainer's graphs there -- an illegal driver call under stream capture, the process aborts.  ``_capture`` collects first and
+    holds the collector off while it captures."""
+    import gc
+    batches = [synthetic_images(8, 32, 300 + k).cuda() for k in range(3)]
+    old = gc.get_threshold()
+    try:
+        for run in range(2):
+            tr = _trainer(tmp_path, 'iqn', f'gc{run}')
+            _load_procedural(tr)
+            tr.enable_graphs()
+            tr._self_cycle = tr                      # (whatever else: this trainer can only be freed by the cyclic collector)
+            gc.set_threshold(1, 1, 1)
+            logs = _loop(tr, [], batches, [5, 6, 7])
+            gc.set_threshold(*old)
+            assert tr._graphs is not None and all(torch.isfinite(torch.as_tensor(list(map(float, l.values())))).all() for l in logs)
+            del tr
+    finally:
+        gc.set_threshold(*old)
+        gc.collect()
