@@ -54,6 +54,10 @@ def parse():
                         'tune: time both, keep the faster')
     p.add_argument('--backend', default='nccl', help='torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the DP code path)')
     p.add_argument('--share-gpu', action='store_true', help='rehearsal only: every rank uses cuda:0')
+    p.add_argument('--rehearse-rccl', action='store_true',
+                   help='N=1 only: a ONE-rank RCCL group with DataParallel(rehearse=True) -- every collective of an N-rank step is '
+                        'issued (bucket all-reduces on the side stream, SyncBN sums inside the graphs) and is the identity; '
+                        'measures what the collectives cost the step apart from the wire')
     return p.parse_args()
 
 
@@ -335,6 +339,12 @@ def main():
     if a.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    rehearse = a.rehearse_rccl and world == 1
+    if rehearse:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', local_rank))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if a.backend == 'nccl':
@@ -345,12 +355,12 @@ def main():
     from tartangan_amd import backend
     K = backend.get()                          # fails loudly without the HIP library
     tr, cfg = make_trainer(a.config, a.trainer, a.batch, 'cuda')
-    if world > 1:
+    if world > 1 or rehearse:
         from tartangan_amd.parallel import DataParallel
         if not a.eager:
             tr.enable_graphs()
         overlap = {'on': True, 'off': False}.get(a.overlap, a.backend == 'nccl')
-        dp = DataParallel(tr, sync_bn=a.sync_bn, overlap=overlap)
+        dp = DataParallel(tr, sync_bn=a.sync_bn, overlap=overlap, rehearse=rehearse)
     elif not a.eager:
         tr.enable_graphs()
     size = tr.g.max_size
@@ -406,12 +416,13 @@ def main():
             'config': {'workload': f'{a.config} SA-GAN {a.trainer} G+D step (R1 penalty, Adam x2, EMA), '
                                    f'{size}x{size} RGB, batch {a.batch}/GPU, global batch {a.batch * world}',
                        'trainer': a.trainer, 'gan_config': a.config, 'global_batch': a.batch * world,
-                       'parallelism': f'dp{world}' + ('' if world == 1 else
+                       'parallelism': f'dp{world}' + ('' if world == 1 and not rehearse else
                                                       f' ({"global-batch (synchronised)" if a.sync_bn else "local-batch"} BatchNorm, '
                                                       f'flat-bucket {dp.collective_name} all-reduce x2'
                                                       f'{", D bucket on a side stream under the G forward" if dp.overlap else ""})'),
                        'hip_graphs': not a.eager,
-                       **({} if world == 1 else {'rccl_ranks': dist.get_world_size(), 'collective_backend': dist.get_backend(),
+                       **({'rehearsal': 'one-rank RCCL group, every collective issued'} if rehearse else {}),
+                       **({} if world == 1 and not rehearse else {'rccl_ranks': dist.get_world_size(), 'collective_backend': dist.get_backend(),
                                                  'sync_bn': bool(a.sync_bn), 'overlap': bool(dp.overlap)})},
             'final_losses': {k: round(v, 6) for k, v in logs.items()},
         }
@@ -454,7 +465,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:       # reported at N = 1 only
             out['cpu_baseline'] = cpu_baseline(a.config, a.trainer, a.cpu_batch or a.batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
 

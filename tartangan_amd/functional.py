@@ -1311,8 +1311,11 @@ class SyncGroup:
     """Handle a BatchNorm2d carries in a data-parallel run with synchronised statistics (parallel.DataParallel(sync_bn=True)):
     every pass all-reduces its per-channel sums over ``group`` (tg_bn_sync_*: local sums -> all-reduce -> finish)."""
 
-    def __init__(self, group, world):
+    def __init__(self, group, world, rehearse=False):
         self.group, self.world = group, int(world)
+        # rehearse: issue the collectives even with ONE rank (parallel.DataParallel(rehearse=True): the RCCL leg of the
+        # step -- in-graph collectives, a communicator of their own -- exercised on a one-GPU box; same numbers)
+        self.active = self.world > 1 or bool(rehearse)
 
     def all_reduce(self, sums):
         import torch.distributed as dist
@@ -1349,13 +1352,13 @@ class _BNAct(Function):
         if groups > 1:
             # the real and the fake batch in one tensor (``Pair``): statistics per half, running statistics updated
             # real-then-fake, num_batches_tracked += 2 -- what the reference's two forwards leave behind
-            if not training or (sync is not None and sync.world > 1) or x.shape[0] != groups * B:
+            if not training or (sync is not None and sync.active) or x.shape[0] != groups * B:
                 raise RuntimeError('grouped BatchNorm: training mode, local statistics, equal groups only')
             sync = None
             ws = _ws(x, K().bn_workspace(B, groups * C, hw))
             K().bn_train_fwd_groups(x, mean, invstd, running_mean, running_var, num_batches_tracked, gamma, beta,
                                     float(slope), float(momentum), float(eps), z, ws, groups, B, C, hw, int(replicate))
-        elif training and sync is not None and sync.world > 1:
+        elif training and sync is not None and sync.active:
             ws = _ws(x, K().bn_workspace(B, C, hw))
             sums = _sums(x, C, 3)
             K().bn_sync_stats_local(x, sums, ws, B, C, hw)
@@ -1492,7 +1495,7 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum
     for a tensor holding every element that many times (see tg_bn_train_stats); only running_var depends on it.
     ``sync``: a ``SyncGroup`` -- batch statistics and backward sums over all ranks' shards (SyncBN)."""
     if _is_pair(x):
-        if training and (sync is None or sync.world <= 1):
+        if training and (sync is None or not sync.active):
             return pair_apply(_BNAct, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope,
                               num_batches_tracked, replicate, None, 1)
         return per_half(batch_norm_act, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope,

@@ -36,12 +36,16 @@ from .optim import flatten_parameters
 
 
 class DataParallel:
-    def __init__(self, trainer, process_group=None, sync_bn=False, overlap=None):
+    def __init__(self, trainer, process_group=None, sync_bn=False, overlap=None, rehearse=False):
         if not dist.is_initialized():
             raise RuntimeError('init torch.distributed first (backend "nccl" = RCCL on ROCm)')
         self.group = process_group
         self.rank = dist.get_rank(process_group)
         self.world = dist.get_world_size(process_group)
+        # ``rehearse``: a ONE-rank group behaves like an N-rank one -- every collective of the step is issued (bucket all-reduces
+        # on the side stream, SyncBN's sums inside the captured passes, the split graphs) and changes nothing.  It is how the
+        # RCCL leg is exercised on a one-GPU box (RCCL refuses two ranks on one device): tests/test_dp_gpu.py.
+        self.multi = self.world > 1 or bool(rehearse)
         self.backend = dist.get_backend(process_group)
         self.trainer = trainer
         self.sync_bn = bool(sync_bn)
@@ -56,14 +60,14 @@ class DataParallel:
         feed.rank, feed.world = self.rank, self.world
         trainer._route_rng_through_feed()       # IQN taus must come through the feed to be sliced per rank
         self.bn_group = None
-        if self.sync_bn and self.world > 1:
+        if self.sync_bn and self.multi:
             # SyncBN's collectives sit INSIDE the passes (with RCCL: captured into the step's graphs) while a gradient bucket
             # may be in flight on the side stream.  Two collectives of ONE communicator issued from independent streams can
             # reach the device in a different order on different ranks, which RCCL/NCCL does not allow (it may hang) -- so
             # the BatchNorm sums get a communicator of their own; the bucket all-reduces keep ``process_group``.
             ranks = dist.get_process_group_ranks(process_group) if process_group is not None else None
             self.bn_group = dist.new_group(ranks=ranks) if self.overlap else process_group
-            handle = TF.SyncGroup(self.bn_group, self.world)
+            handle = TF.SyncGroup(self.bn_group, self.world, rehearse=self.multi)
             for net in (trainer.g, trainer.d):
                 for m in net.modules():
                     if isinstance(m, BatchNorm2d):
@@ -77,7 +81,7 @@ class DataParallel:
     @property
     def capturable(self):
         """May a step with in-graph collectives (SyncBN) be captured into HIP graphs?  Only RCCL enqueues device work."""
-        return not (self.sync_bn and self.world > 1) or self.backend == 'nccl'
+        return not (self.sync_bn and self.multi) or self.backend == 'nccl'
 
     def sync_state(self):
         """Make every rank start from rank 0's parameters and buffers."""
@@ -94,13 +98,13 @@ class DataParallel:
 
     def all_reduce_mean(self, flat_grads):
         """Blocking form (serial schedule)."""
-        if self.world > 1:
+        if self.multi:
             self._reduce_now(flat_grads)
 
     def begin_all_reduce(self, key, flat_grads):
         """Start averaging ``flat_grads`` over the ranks; ``finish_all_reduce(key)`` must run before anything reads
         them.  With a side stream the collective runs beside whatever the compute stream does in between."""
-        if self.world == 1:
+        if not self.multi:
             return
         if self._side is None or not self.overlap:
             self._reduce_now(flat_grads)
@@ -119,7 +123,7 @@ class DataParallel:
         (same decision on every rank: the timings are max-reduced).  Both schedules give identical numbers, so this is
         purely a speed choice -- a guard against a collective library whose side-stream path misbehaves next to graph replay."""
         import time
-        if self.world == 1 or self._side is None:
+        if not self.multi or self._side is None:
             return self.overlap
         took = []
         for mode in (True, False):

@@ -363,7 +363,7 @@ class CNNTrainer(Trainer):
         g1, g2a, g2b, g3 = (torch.cuda.CUDAGraph() for _ in range(4))
         # with a process group alive, its watchdog thread polls events; only this thread's calls matter here
         kw = dict(pool=pool)
-        split = self.data_parallel is not None and self.data_parallel.world > 1
+        split = self.data_parallel is not None and self.data_parallel.multi
         if split:
             kw['capture_error_mode'] = 'thread_local'
         with torch.cuda.graph(g1, **kw):

@@ -126,3 +126,74 @@ def test_sync_bn_ranks_reproduce_the_reference_fixture_at_the_global_batch(case,
     for got, name in zip(res['losses'][0], ('g_loss', 'd_loss', 'gp')):
         want = fx['steps'][0][name]
         assert abs(got - want) <= _loss_tol(case, name) * max(abs(want), 1e-6), (case, name, got, want)
+
+
+def _rccl_worker(port, kind, batch, sync_bn, graphs, steps, out):
+    """ONE rank on RCCL with ``rehearse=True``: every collective of an N-rank step is issued (and is the identity)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    from tartangan_amd.parallel import DataParallel
+    tr = _build(kind, batch)
+    if graphs:
+        tr.enable_graphs()
+    dp = DataParallel(tr, sync_bn=sync_bn, rehearse=True)        # overlap: the library default with RCCL (side stream)
+    imgs = synthetic_images(batch, 32, 4321).cuda()
+    torch.manual_seed(1234)
+    import warnings
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        logs = [tr.train_batch(imgs) for _ in range(steps)]
+    torch.cuda.synchronize()
+    held = getattr(tr, '_graphs', None)
+    out.put(dict(losses=[[l['g_loss'], l['d_loss'], l['gp']] for l in logs], d=tr.optimizer_d.flat.cpu().tolist(),
+                 g=tr.optimizer_g.flat.cpu().tolist(), graphed=held is not None, split=held is not None and held[1] is not None,
+                 overlap=dp.overlap, backend=dp.backend, own_bn_group=dp.bn_group is not None and dp.bn_group is not dp.group,
+                 warnings=[str(w.message) for w in caught if 'capture' in str(w.message).lower()],
+                 rng_after=float(torch.rand(1))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rccl_run(kind, sync_bn, graphs, steps=4):
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), kind, 8, sync_bn, graphs, steps, out))
+    p.start()
+    res = out.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert res['backend'] == 'nccl' and res['overlap'] and not res['warnings'], res
+    assert res['own_bn_group'] == sync_bn
+    return res
+
+
+@pytest.mark.parametrize('kind,sync_bn', [('cnn', False), ('cnn', True), ('iqn', True)])
+def test_rccl_leg_single_rank_rehearsal(kind, sync_bn):
+    """The RCCL leg on the one-GPU box: a ONE-rank ``nccl`` process group with ``DataParallel(rehearse=True)`` issues every
+    collective an N-rank step issues -- the two flat-bucket all-reduces on the side stream next to the replaying graphs (four-graph
+    split), and with SyncBN the per-layer sums all-reduced INSIDE the captured passes on a communicator of their own.
+    Graph replay must equal the eager schedule of the same collectives bit for bit; with local BatchNorm both must equal the
+    plain single-process step bit for bit (the same kernels); with SyncBN the plain step is another set of kernels (sums in
+    another order) and this model at batch 8 amplifies that -- the 1e-4 pins of SyncBN against the full batch are the
+    fixture tests above, here it is a sanity bound."""
+    graphed = _rccl_run(kind, sync_bn, True)
+    eager = _rccl_run(kind, sync_bn, False)
+    assert graphed['graphed'] and graphed['split'] and not eager['graphed']
+    assert graphed['losses'] == eager['losses'] and graphed['rng_after'] == eager['rng_after']
+    assert graphed['d'] == eager['d'] and graphed['g'] == eager['g']
+    single = _build(kind, 8)
+    single.enable_graphs()
+    imgs = synthetic_images(8, 32, 4321).cuda()
+    torch.manual_seed(1234)
+    want = [single.train_batch(imgs) for _ in range(4)]
+    assert graphed['rng_after'] == float(torch.rand(1))
+    tol = [1e-3, 1e-2, 5e-2, 2e-1] if sync_bn else [0.0] * 4        # free-running steps of a chaotic toy model drift apart
+    for got, w, t in zip(graphed['losses'], want, tol):
+        for x, name in zip(got, ('g_loss', 'd_loss', 'gp')):
+            assert abs(x - w[name]) <= t * max(abs(w[name]), 1e-6), (name, got, w)
+    if not sync_bn:
+        assert torch.equal(torch.tensor(graphed['d']), single.optimizer_d.flat.cpu())
+        assert torch.equal(torch.tensor(graphed['g']), single.optimizer_g.flat.cpu())
