@@ -21,6 +21,7 @@
 //    64 pixels, waves split K       : G4k G8k G16k  -- small-spatial layers still fill the chip
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -192,6 +193,8 @@ struct PatchStager {
     }
   }
 
+  // CISX: per-channel stride of the LDS image (the Winograd kernel keeps its own: wino.h)
+  template <int CISX = P::CIS>
   __device__ __forceinline__ void store(float* __restrict__ lds) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -199,7 +202,7 @@ struct PatchStager {
       if (e < ROWS * Q) {
         const int q = e % Q, row = e / Q;
         const int ci = row / P::ROWS_PER_CI, lrow = row % P::ROWS_PER_CI;
-        *reinterpret_cast<float4*>(lds + ci * P::CIS + lrow * P::PWS + P::IOFF + 4 * q) = v[i];
+        *reinterpret_cast<float4*>(lds + ci * CISX + lrow * P::PWS + P::IOFF + 4 * q) = v[i];
       }
     }
     if constexpr (KGeom<KS>::HALO == 3) {
@@ -209,7 +212,7 @@ struct PatchStager {
         if (e < NHALO) {
           const int row = e >> 1;
           const int ci = row / P::ROWS_PER_CI, lrow = row % P::ROWS_PER_CI;
-          lds[ci * P::CIS + lrow * P::PWS + ((e & 1) ? P::IOFF + G::TW : P::IOFF - 1)] = hv[i];
+          lds[ci * CISX + lrow * P::PWS + ((e & 1) ? P::IOFF + G::TW : P::IOFF - 1)] = hv[i];
         }
       }
     }
@@ -612,6 +615,8 @@ __device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstl
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds_wave_base, uint32_t voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
+
+#include "wino.h"
 
 #ifdef TG_DIAG_STAMPS
 // Diagnostic build (make -C tartangan_amd/csrc diag -> libtartangan_amd_diag.so, loaded with TG_LIBRARY=...): every workgroup
@@ -2997,10 +3002,51 @@ static int conv1x1_mode() {
   return v;
 }
 
+// ---- Winograd F(2x2, 3x3) dispatch (wino.h).  TG_CONV_WINO=0 disables it, 2 takes every eligible shape (tests), 1 (default)
+// only the launches that fill the chip: 64-tile workgroups on 8x8 / 4x4 planes give too few workgroups at the step's batch.
+static int wino_mode() {
+  static const int v = [] { const char* e = getenv("TG_CONV_WINO"); return e ? atoi(e) : 1; }();
+  return v;
+}
+template <class G, bool DGRAD>
+static int launch_wino_geo(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st,
+                           int64_t min_wgs) {
+  const int tiles = num_tiles<G>(s.B, s.H, s.W);
+  const int flags = (tiles % 8 == 0) ? 1 : 0;
+  if (s.Cout > 16 && (int64_t)tiles * ((s.Cout + 31) / 32) >= min_wgs)
+    conv_wino_dma_kernel<G, 2, DGRAD><<<dim3(tiles, (s.Cout + 31) / 32), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, flags);
+  else if ((int64_t)tiles * ((s.Cout + 15) / 16) >= min_wgs)
+    conv_wino_dma_kernel<G, 1, DGRAD><<<dim3(tiles, (s.Cout + 15) / 16), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, flags);
+  else
+    return -1;
+  return tg_launch_status();
+}
+// -> true when the Winograd kernel took the launch
+template <bool DGRAD>
+static bool try_launch_wino(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st,
+                            int* rc) {
+  const int mode = wino_mode();
+  if (!mode) return false;
+  if (s.os != 1 || s.Cin % WINO_CK != 0 || s.Cout < 16 || s.W % 4 != 0 || !tg_aligned16(x) || !tg_aligned16(y) ||
+      (residual && !tg_aligned16(residual)) || (int64_t)s.B * s.Cin * s.H * s.W * 4 >= (1ll << 31))
+    return false;
+  const int64_t min_wgs = (mode == 2) ? 1 : 256;
+  // (64-tile workgroups on 8x8 / 4x4 planes give too few workgroups at the step's batch: mode 2 only)
+  int r = -1;
+  if (s.H % 8 == 0 && s.W % 32 == 0) r = launch_wino_geo<GX, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
+  else if (s.H == 16 && s.W == 16) r = launch_wino_geo<G16, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
+  else if (mode == 2 && s.H == 8 && s.W == 8) r = launch_wino_geo<G8, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
+  else if (mode == 2 && s.H == 4 && s.W == 4) r = launch_wino_geo<G4, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
+  if (r < 0) return false;
+  *rc = r;
+  return true;
+}
+
 template <int KS, bool DGRAD>
 int launch_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st) {
   if constexpr (KS == 3) {
     int rc = 0;
+    if (try_launch_wino<DGRAD>(x, w, bias, residual, y, s, st, &rc)) return rc;
     if (try_launch_dma<DGRAD>(x, w, bias, residual, y, s, st, &rc)) return rc;
   }
   // small layers: if 256-pixel tiles cannot even give every other CU a workgroup, use 64-pixel tiles whose waves

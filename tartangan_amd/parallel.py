@@ -36,7 +36,7 @@ from .optim import flatten_parameters
 
 
 class DataParallel:
-    def __init__(self, trainer, process_group=None, sync_bn=False, overlap=None, rehearse=False):
+    def __init__(self, trainer, process_group=None, sync_bn=False, overlap=None, rehearse=False, graph_buckets=True):
         if not dist.is_initialized():
             raise RuntimeError('init torch.distributed first (backend "nccl" = RCCL on ROCm)')
         self.group = process_group
@@ -49,10 +49,13 @@ class DataParallel:
         self.backend = dist.get_backend(process_group)
         self.trainer = trainer
         self.sync_bn = bool(sync_bn)
+        self.graph_buckets = bool(graph_buckets)     # False: bucket all-reduces stay eager calls between graph replays
         on_device = str(trainer.device) != 'cpu'
-        # default: overlap with RCCL; gloo's device path (host staging with blocking synchronisation) stalls for seconds when
-        # a side-stream collective meets a replaying graph (measured: 23 ms -> 3 s per step with two ranks on one GPU)
-        self.overlap = (on_device and self.backend == 'nccl') if overlap is None else bool(overlap)
+        # default: the SERIAL schedule.  Measured with RCCL on one rank (bench.py --rehearse-rccl, DESIGN.md "Multi-GPU"): the
+        # side-stream schedule costs the step 0.4 ms (four graphs, two stream joins) and has nothing left to hide the D bucket
+        # under since the generator's two forwards share one pass; gloo's device path (host staging with blocking
+        # synchronisation) even stalls for seconds when a side-stream collective meets a replaying graph.
+        self.overlap = False if overlap is None else bool(overlap)
         self._side = torch.cuda.Stream() if on_device else None
         self._pending = {}
         trainer.data_parallel = self
@@ -82,6 +85,12 @@ class DataParallel:
     def capturable(self):
         """May a step with in-graph collectives (SyncBN) be captured into HIP graphs?  Only RCCL enqueues device work."""
         return not (self.sync_bn and self.multi) or self.backend == 'nccl'
+
+    @property
+    def buckets_in_graph(self):
+        """Serial schedule on RCCL: the gradient-bucket all-reduces are device work on the compute stream and are captured
+        into the step's graphs like every other launch (no eager call between graph replays)."""
+        return self.multi and not self.overlap and self.backend == 'nccl' and self.graph_buckets
 
     def sync_state(self):
         """Make every rank start from rank 0's parameters and buffers."""

@@ -363,11 +363,18 @@ class CNNTrainer(Trainer):
         g1, g2a, g2b, g3 = (torch.cuda.CUDAGraph() for _ in range(4))
         # with a process group alive, its watchdog thread polls events; only this thread's calls matter here
         kw = dict(pool=pool)
-        split = self.data_parallel is not None and self.data_parallel.multi
-        if split:
+        dp = self.data_parallel
+        multi = dp is not None and dp.multi
+        # serial schedule on RCCL: the two bucket all-reduces are captured INTO the graphs (three graphs, as on one GPU);
+        # side-stream schedule, or a host-staged backend (gloo): the graphs are cut where the collectives start / join
+        inside = multi and dp.buckets_in_graph
+        split = multi and not inside
+        if multi:
             kw['capture_error_mode'] = 'thread_local'
         with torch.cuda.graph(g1, **kw):
             self._out_d = self._d_phase(self._static_imgs)
+            if inside:
+                dp.all_reduce_mean(self.optimizer_d.grads)
         if split:           # the generator forward in a graph of its own: it runs while the D bucket is all-reduced
             with torch.cuda.graph(g2a, **kw):
                 fake = self._g_forward(len(imgs))
@@ -379,11 +386,14 @@ class CNNTrainer(Trainer):
             with torch.cuda.graph(g2b, **kw):
                 self.optimizer_d.apply()
                 self._out_g = self._g_phase(len(imgs))
+                if inside:
+                    dp.all_reduce_mean(self.optimizer_g.grads)
         with torch.cuda.graph(g3, **kw):
             self.optimizer_g.apply()
             self.update_target_generator()
             # the losses side by side in one static buffer: the replayed step reads back ONE tensor, no launch of its own
             self._out_losses = torch.stack([v for v in (self._out_g, self._out_d[0], self._out_d[1]) if v is not None])
+        self._buckets_in_graph = inside
         self._graphs = (g1, g2a, g2b, g3)
         feed.cursor = 0
 
@@ -396,6 +406,9 @@ class CNNTrainer(Trainer):
         gen = (self.optimizer_d.ensure_bound(), self.optimizer_g.ensure_bound())
         if self._graphs is not None and gen != self._graph_gen:
             self._graphs = None                                # parameter buckets were rebuilt: recapture
+        dp = self.data_parallel
+        if self._graphs is not None and dp is not None and dp.multi and dp.buckets_in_graph != self._buckets_in_graph:
+            self._graphs = None                                # the collective schedule changed (autotune_overlap): recapture
         if self._graphs is None:                               # call 2: capture (nothing executes yet)
             try:
                 self._capture(imgs)
@@ -416,6 +429,11 @@ class CNNTrainer(Trainer):
         self._static_imgs.copy_(imgs, non_blocking=True)
         self.optimizer_d.advance(checked=True)
         self.optimizer_g.advance(checked=True)
+        if self._buckets_in_graph:                             # (RCCL, serial schedule: the collectives replay with the graphs)
+            g1.replay()
+            g2b.replay()
+            g3.replay()
+            return self._out_losses
         g1.replay()
         self._begin_reduce('d', self.optimizer_d)
         if g2a is not None:

@@ -128,7 +128,7 @@ def test_sync_bn_ranks_reproduce_the_reference_fixture_at_the_global_batch(case,
         assert abs(got - want) <= _loss_tol(case, name) * max(abs(want), 1e-6), (case, name, got, want)
 
 
-def _rccl_worker(port, kind, batch, sync_bn, graphs, steps, out):
+def _rccl_worker(port, kind, batch, sync_bn, graphs, side, steps, out):
     """ONE rank on RCCL with ``rehearse=True``: every collective of an N-rank step is issued (and is the identity)."""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -139,7 +139,7 @@ def _rccl_worker(port, kind, batch, sync_bn, graphs, steps, out):
     tr = _build(kind, batch)
     if graphs:
         tr.enable_graphs()
-    dp = DataParallel(tr, sync_bn=sync_bn, rehearse=True)        # overlap: the library default with RCCL (side stream)
+    dp = DataParallel(tr, sync_bn=sync_bn, overlap=side, rehearse=True)
     imgs = synthetic_images(batch, 32, 4321).cuda()
     torch.manual_seed(1234)
     import warnings
@@ -149,7 +149,7 @@ def _rccl_worker(port, kind, batch, sync_bn, graphs, steps, out):
     torch.cuda.synchronize()
     held = getattr(tr, '_graphs', None)
     out.put(dict(losses=[[l['g_loss'], l['d_loss'], l['gp']] for l in logs], d=tr.optimizer_d.flat.cpu().tolist(),
-                 g=tr.optimizer_g.flat.cpu().tolist(), graphed=held is not None, split=held is not None and held[1] is not None,
+                 g=tr.optimizer_g.flat.cpu().tolist(), graphed=held is not None, split=held is not None and held[1] is not None, inside=getattr(tr, '_buckets_in_graph', None),
                  overlap=dp.overlap, backend=dp.backend, own_bn_group=dp.bn_group is not None and dp.bn_group is not dp.group,
                  warnings=[str(w.message) for w in caught if 'capture' in str(w.message).lower()],
                  rng_after=float(torch.rand(1))))
@@ -157,31 +157,32 @@ def _rccl_worker(port, kind, batch, sync_bn, graphs, steps, out):
     dist.destroy_process_group()
 
 
-def _rccl_run(kind, sync_bn, graphs, steps=4):
+def _rccl_run(kind, sync_bn, graphs, side, steps=4):
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), kind, 8, sync_bn, graphs, steps, out))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), kind, 8, sync_bn, graphs, side, steps, out))
     p.start()
     res = out.get(timeout=600)
     p.join(120)
     assert p.exitcode == 0
-    assert res['backend'] == 'nccl' and res['overlap'] and not res['warnings'], res
-    assert res['own_bn_group'] == sync_bn
+    assert res['backend'] == 'nccl' and res['overlap'] == side and not res['warnings'], res
+    assert res['own_bn_group'] == (sync_bn and side)
     return res
 
 
-@pytest.mark.parametrize('kind,sync_bn', [('cnn', False), ('cnn', True), ('iqn', True)])
-def test_rccl_leg_single_rank_rehearsal(kind, sync_bn):
+@pytest.mark.parametrize('kind,sync_bn,side', [('cnn', False, False), ('cnn', False, True), ('cnn', True, False), ('iqn', True, True)])
+def test_rccl_leg_single_rank_rehearsal(kind, sync_bn, side):
     """The RCCL leg on the one-GPU box: a ONE-rank ``nccl`` process group with ``DataParallel(rehearse=True)`` issues every
-    collective an N-rank step issues -- the two flat-bucket all-reduces on the side stream next to the replaying graphs (four-graph
-    split), and with SyncBN the per-layer sums all-reduced INSIDE the captured passes on a communicator of their own.
+    collective an N-rank step issues -- the two flat-bucket all-reduces, either captured into the step's three graphs (the serial
+    schedule, the default) or on the side stream next to the replaying graphs (four-graph split) -- and with SyncBN the per-layer
+    sums all-reduced INSIDE the captured passes (on a communicator of their own when buckets fly on the side stream).
     Graph replay must equal the eager schedule of the same collectives bit for bit; with local BatchNorm both must equal the
     plain single-process step bit for bit (the same kernels); with SyncBN the plain step is another set of kernels (sums in
     another order) and this model at batch 8 amplifies that -- the 1e-4 pins of SyncBN against the full batch are the
     fixture tests above, here it is a sanity bound."""
-    graphed = _rccl_run(kind, sync_bn, True)
-    eager = _rccl_run(kind, sync_bn, False)
-    assert graphed['graphed'] and graphed['split'] and not eager['graphed']
+    graphed = _rccl_run(kind, sync_bn, True, side)
+    eager = _rccl_run(kind, sync_bn, False, side)
+    assert graphed['graphed'] and graphed['split'] == side and graphed['inside'] == (not side) and not eager['graphed']
     assert graphed['losses'] == eager['losses'] and graphed['rng_after'] == eager['rng_after']
     assert graphed['d'] == eager['d'] and graphed['g'] == eager['g']
     single = _build(kind, 8)
