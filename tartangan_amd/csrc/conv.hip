@@ -2795,8 +2795,35 @@ static bool s2_dma_ok(const void* x, const void* w, const Shape& s, int hi_chann
 static int dma_prio();
 static bool s2_single_buffer();
 
+static int wino_mode();
+// AvgPool2d(2) o conv3x3 in its 9-frequency form (conv_poolwino_dma_kernel, wino.h) -> true when it took the launch
+static bool try_launch_poolwino(const float* x, const float* w4, const float* bias, const float* residual, float* y, const Shape& s,
+                                int vx, hipStream_t st) {
+  const int mode = wino_mode();
+  if (!mode || !vx || s.Cin % WINO_CK != 0 || s.Cout < 16 || s.W % 4 != 0 || !tg_aligned16(y) || (residual && !tg_aligned16(residual)) ||
+      (int64_t)s.B * s.Cin * s.H * s.W * 16 >= (1ll << 31))
+    return false;
+  const int Hh = 2 * s.H, Wh = 2 * s.W;
+  const int cob = (s.Cout + 31) / 32;
+  const int64_t min_wgs = (mode == 2) ? 1 : 256;
+  if (Hh % 8 == 0 && Wh % 32 == 0) {
+    const int tiles = num_tiles<GX>(s.B, Hh, Wh);
+    if ((int64_t)tiles * cob < min_wgs) return false;
+    conv_poolwino_dma_kernel<GX, 2><<<dim3(tiles, cob), CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, (tiles % 8 == 0) ? 1 : 0);
+    return true;
+  }
+  if (Hh == 16 && Wh == 16) {
+    const int tiles = num_tiles<G16>(s.B, Hh, Wh);
+    if ((int64_t)tiles * cob < min_wgs) return false;
+    conv_poolwino_dma_kernel<G16, 2><<<dim3(tiles, cob), CT_THREADS, 0, st>>>(x, w4, bias, residual, y, s, (tiles % 8 == 0) ? 1 : 0);
+    return true;
+  }
+  return false;
+}
+
 static void launch_upT(GeoId g, const float* x, const float* w4, const float* bias, const float* residual, float* y, Shape s,
                        int vx, int vw, hipStream_t st) {
+  if (try_launch_poolwino(x, w4, bias, residual, y, s, vx, st)) return;
   const int cot = (s.Cout + 15) / 16;
   if (vx && vw && s2_dma_ok(x, w4, s, s.Cin)) {            // LDS-DMA staged forms
     s.prio = dma_prio();
@@ -3013,6 +3040,11 @@ static int launch_wino_geo(const float* x, const float* w, const float* bias, co
                            int64_t min_wgs) {
   const int tiles = num_tiles<G>(s.B, s.H, s.W);
   const int flags = (tiles % 8 == 0) ? 1 : 0;
+  if (s.Cin == 4) {                      // the composed from-RGB layer: one 4-channel chunk
+    if (s.Cout > 16 || (int64_t)tiles < min_wgs) return -1;
+    conv_wino_dma_kernel<G, 1, DGRAD, 4><<<dim3(tiles, 1), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, flags);
+    return tg_launch_status();
+  }
   if (s.Cout > 16 && (int64_t)tiles * ((s.Cout + 31) / 32) >= min_wgs)
     conv_wino_dma_kernel<G, 2, DGRAD><<<dim3(tiles, (s.Cout + 31) / 32), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, flags);
   else if ((int64_t)tiles * ((s.Cout + 15) / 16) >= min_wgs)
@@ -3027,7 +3059,8 @@ static bool try_launch_wino(const float* x, const float* w, const float* bias, c
                             int* rc) {
   const int mode = wino_mode();
   if (!mode) return false;
-  if (s.os != 1 || s.Cin % WINO_CK != 0 || s.Cout < 16 || s.W % 4 != 0 || !tg_aligned16(x) || !tg_aligned16(y) ||
+  // channel counts: whole 8-channel chunks (or the 4-channel image layer); >= 4 output channels (a 16-wide block is masked)
+  if (s.os != 1 || (s.Cin % WINO_CK != 0 && s.Cin != 4) || s.Cout < 4 || s.W % 4 != 0 || !tg_aligned16(x) || !tg_aligned16(y) ||
       (residual && !tg_aligned16(residual)) || (int64_t)s.B * s.Cin * s.H * s.W * 4 >= (1ll << 31))
     return false;
   const int64_t min_wgs = (mode == 2) ? 1 : 256;

@@ -65,7 +65,7 @@ template <> struct WinoMap<G4> {
   __device__ __forceinline__ static void at(int w, int i, int& img, int& y0, int& x0) { img = 4 * w + (i >> 2); y0 = 2 * ((i >> 1) & 1); x0 = 2 * (i & 1); }
 };
 
-constexpr int WINO_CK = 8;      // input channels per staged chunk (two k-steps of the 16x16x4 MFMA)
+constexpr int WINO_CK = 8;      // input channels per staged chunk (two k-steps of the 16x16x4 MFMA); 4 for a 4-channel input
 constexpr int WINO_US = 20;     // floats per (channel, output channel) slot of the transformed filter: 16 + 4 of padding
                                 // (a ds_read_b128 lane group -- 8 lanes of one k, 8 of the next -- starts on 16 distinct 16-byte slots)
 
@@ -83,12 +83,13 @@ template <class G> struct WinoPatch {
   static_assert(CIS % 64 == 32 && RAW % 4 == 0, "channel stride");
 };
 
-template <class G, int NB, bool DGRAD>
+template <class G, int NB, bool DGRAD, int CK = WINO_CK>
 __global__ void __launch_bounds__(CT_THREADS, (G::NI > 1) ? 1 : (NB == 1) ? 3 : 2)
 conv_wino_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                      const float* __restrict__ residual, float* __restrict__ y, Shape s, int flags) {
   using P = WinoPatch<G>;
-  constexpr int CK = WINO_CK, NT = 16 * NB, US = WINO_US, CIS = P::CIS;
+  constexpr int NT = 16 * NB, US = WINO_US, CIS = P::CIS;
+  static_assert(CK % 4 == 0, "whole k-steps");
   constexpr int PCH = CK * P::CPC, PCHP = dma_pad(PCH);           // 16-byte chunks of a patch buffer, padded to whole wave pieces
   constexpr int NVP = (PCHP + CT_THREADS - 1) / CT_THREADS;
   constexpr int PBUF = PCHP * 4, UBUF = CK * NT * US;
@@ -282,5 +283,180 @@ conv_wino_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, c
       for (int a = 0; a < 2; ++a)
         *reinterpret_cast<float4*>(y + plane * HW + (int64_t)(hh + a) * s.W + ww) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
     }
+  }
+}
+
+// =========================================================================== AvgPool2d(2) o conv3x3 (and the up-conv's input gradient)
+// out[i][j] = 1/4 sum_{a,b in {0,1}} conv3x3(x)[2i+a][2j+b]  =  1/4 (A 1)^T [ (G g G^T) .* (B^T d B) ] (A 1)  over the SAME 4x4
+// stride-2 input tiles as above.  A 1 = (1, 2, 0, -1): frequency row / column 2 drops out -- 9 multiplies per output and channel
+// pair where the 4x4 stride-2 form (conv_upT_dma_kernel) does 16 and the unfused pair 36 -- and the output transform is a
+// plain weighted sum, so it folds into the filter: the 9 frequency products accumulate into ONE accumulator (a GEMM with
+// K = 9 Cin), no output transform at all.  The filter arrives as the 4x4 stride-2 form w4[n][k][u][v] = sum_{r in S(u), s in S(v)}
+// c g[r][s], S = {0},{0,1},{1,2},{2} (tg_poolconv3x3_weights: c = 1/4; tg_upconv3x3_weights_t: the transposed flipped filter,
+// c = 1), from which U' = c (A1 A1^T) .* (G g G^T) is sums of its entries at rows / columns {0, 2, 3} -- no subtraction of
+// nearly equal numbers:   U'[0] = (w00, w00+w02, -w03)   U'[1] = (w00+w20, w00+w02+w20+w22, -(w03+w23))   U'[3] = (-w30, -(w30+w32), w33).
+// Geometry: G tiles the HIGH-resolution input plane (2H x 2W); a workgroup makes 64 outputs x 16 NB channels.
+constexpr int WINO_PS = 12;     // floats per (channel, output channel) slot of U': 9 + 3 of padding (48 bytes: conflict-free b128)
+
+template <class G, int NB>
+__global__ void __launch_bounds__(CT_THREADS, (G::NI > 1) ? 1 : 3)
+conv_poolwino_dma_kernel(const float* __restrict__ x, const float* __restrict__ w4, const float* __restrict__ bias,
+                         const float* __restrict__ residual, float* __restrict__ y, Shape s /* H x W: the LOW-resolution plane */,
+                         int flags) {
+  using P = WinoPatch<G>;
+  constexpr int CK = WINO_CK, NT = 16 * NB, US = WINO_PS, CIS = P::CIS;
+  constexpr int PCH = CK * P::CPC, PCHP = dma_pad(PCH);
+  constexpr int NVP = (PCHP + CT_THREADS - 1) / CT_THREADS;
+  constexpr int PBUF = PCHP * 4, UBUF = CK * NT * US;
+  constexpr int FPT = (CK * NT + CT_THREADS - 1) / CT_THREADS;     // filter pairs per thread
+  __shared__ __attribute__((aligned(16))) float pl[2 * PBUF];
+  __shared__ __attribute__((aligned(16))) float ul[2 * UBUF];
+
+  const int lane = threadIdx.x & 63, wave = wave_index();
+  const int Hh = 2 * s.H, Wh = 2 * s.W;                            // the input plane
+  int bid = blockIdx.x;
+  if (flags & 1) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const TileCoord tc = decode_tile<G>(bid, Hh, Wh);                // (high-resolution coordinates)
+  const int co0 = blockIdx.y * NT;
+  const uint32_t HWp = (uint32_t)(Hh * Wh);
+
+  uint32_t poff[NVP];
+#pragma unroll
+  for (int i = 0; i < NVP; ++i) {
+    const int e = i * CT_THREADS + threadIdx.x;
+    const int ci = e / P::CPC, rem = e % P::CPC;
+    const int row = rem / P::QR, q = rem % P::QR;
+    const int pimg = row / P::PH, r = row % P::PH;
+    const int hh = tc.h0 + r - 1, ww = tc.w0 - 4 + 4 * q;
+    const bool ok = (e < PCH) && (rem < P::RAW / 4) && (tc.b0 + pimg < s.B) && (hh >= 0) && (hh < Hh) && (ww >= 0) && (ww < Wh);
+    poff[i] = ok ? (__umul24(__umul24(pimg, s.Cin) + ci, HWp) + __umul24(hh, Wh) + ww) << 2 : DMA_OOB;
+  }
+  const char* xb = reinterpret_cast<const char*>(x) + ((int64_t)tc.b0 * s.Cin * HWp) * 4;
+  int64_t xbytes = (int64_t)(s.B - tc.b0) * s.Cin * HWp * 4;
+  const int64_t xstep = (int64_t)CK * HWp * 4;
+  auto issue_patch = [&](float* buf) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xb), 0, (int)xbytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NVP; ++i)
+      if ((i + 1) * CT_THREADS <= PCHP || i * CT_THREADS + wave * 64 < PCHP)      // (scalar)
+        dma16(rx, buf + (i * CT_THREADS + wave * 64) * 4, poff[i]);
+    xb += xstep; xbytes -= xstep;
+  };
+
+  const int mi = lane & 15, kk = lane >> 4;
+  int img, y0, x0;
+  WinoMap<G>::at(wave, mi, img, y0, x0);
+  const int a_off = (img * P::PH + y0) * P::PWS + x0 + 2 + kk * CIS;
+  const int b_off = (kk * NT + mi) * US;
+
+  float g9[FPT][9];                       // w4 at rows / columns {0, 2, 3}
+  auto load_filter = [&](int c0) {
+#pragma unroll
+    for (int t = 0; t < FPT; ++t) {
+      const int e = t * CT_THREADS + threadIdx.x;
+      const int fn = e % NT, fk = e / NT;
+      const bool ok = (e < CK * NT) && (co0 + fn < s.Cout) && (c0 + fk < s.Cin);
+      const float* src = w4 + ((int64_t)(co0 + fn) * s.Cin + (c0 + fk)) * 16;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g9[t][a * 3 + b] = ok ? src[(a == 0 ? 0 : a + 1) * 4 + (b == 0 ? 0 : b + 1)] : 0.f;
+    }
+  };
+  auto store_filter = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < FPT; ++t) {
+      const int e = t * CT_THREADS + threadIdx.x;
+      if (e < CK * NT) {
+        const float* g = g9[t];           // g[a*3+b] = w4[{0,2,3}[a]][{0,2,3}[b]]
+        float* dst = ul + buf * UBUF + e * US;
+        const float r0 = g[0] + g[1], r1 = g[3] + g[4];
+        *reinterpret_cast<float4*>(dst) = make_float4(g[0], r0, -g[2], g[0] + g[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(r0 + r1, -(g[2] + g[5]), -g[6], -(g[6] + g[7]));
+        dst[8] = g[8];
+      }
+    }
+  };
+
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue_patch(pl);
+  load_filter(0);
+  store_filter(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (CK < s.Cin) {
+    issue_patch(pl + PBUF);
+    load_filter(CK);
+  }
+
+  int buf = 0;
+  for (int c0 = 0; c0 < s.Cin; c0 += CK, buf ^= 1) {
+    const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(pl + buf * PBUF + a_off);
+    const float* pb = ul + buf * UBUF + b_off;
+#pragma unroll
+    for (int ks = 0; ks < CK / 4; ++ks) {
+      f32x4 ua[NB], ubb[NB];
+      float uc[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float* q = pb + (ks * 4 * NT + nb * 16) * US;
+        ua[nb] = *reinterpret_cast<const f32x4*>(q);
+        ubb[nb] = *reinterpret_cast<const f32x4*>(q + 4);
+        uc[nb] = q[8];
+      }
+      float d[4][4];
+      {
+        f32x2 p[4][3];
+        lds_read_patch<P::PWS * 4>(pa + ks * 4 * CIS * 4, p);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { d[r][0] = p[r][0].y; d[r][1] = p[r][1].x; d[r][2] = p[r][1].y; d[r][3] = p[r][2].x; }
+      }
+      float t[3][4], v[9];                // rows / columns {0, 1, 3} of B^T d B
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { t[0][c] = d[0][c] - d[2][c]; t[1][c] = d[1][c] + d[2][c]; t[2][c] = d[1][c] - d[3][c]; }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { v[a * 3] = t[a][0] - t[a][2]; v[a * 3 + 1] = t[a][1] + t[a][2]; v[a * 3 + 2] = t[a][1] - t[a][3]; }
+#pragma unroll
+      for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float u = f < 4 ? ua[nb][f] : f < 8 ? ubb[nb][f - 4] : uc[nb];
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[f], u, acc[nb], 0, 0, 0);
+        }
+    }
+    if (c0 + CK < s.Cin) {
+      store_filter(buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (c0 + 2 * CK < s.Cin) {
+        issue_patch(pl + buf * PBUF);
+        load_filter(c0 + 2 * CK);
+      }
+    }
+  }
+
+  // ---- epilogue: lane (q = lane / 16, j = lane % 16) holds outputs 4q .. 4q+3 of its wave's strip -- four x-adjacent low-resolution pixels
+  const int q = kk, j = mi;
+  int ti, ty, tx;
+  WinoMap<G>::at(wave, 4 * q, ti, ty, tx);
+  const int b = tc.b0 + ti;
+  if (b >= s.B) return;
+  const int hh = (tc.h0 + ty) >> 1, ww = (tc.w0 + tx) >> 1;
+  const uint32_t HW = (uint32_t)(s.H * s.W);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int co = co0 + nb * 16 + j;
+    if (co >= s.Cout) continue;
+    const float bv = bias ? bias[co] : 0.f;
+    const int64_t off = ((int64_t)b * s.Cout + co) * HW + (int64_t)hh * s.W + ww;
+    float4 o = make_float4(acc[nb][0] + bv, acc[nb][1] + bv, acc[nb][2] + bv, acc[nb][3] + bv);
+    if (residual) {
+      const float4 rr = *reinterpret_cast<const float4*>(residual + off);
+      o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+    }
+    *reinterpret_cast<float4*>(y + off) = o;
   }
 }

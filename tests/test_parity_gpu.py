@@ -36,12 +36,17 @@ def hip_backend():
 # c128big_cnn_b8 (1024-channel layers): d_loss and gp agree at 1e-6, but g_loss = 0.0107 (a saturated discriminator, taken after
 # D's Adam step) spans 7.6e-4 relative over six oracle runs with 1e-7 input noise, and the 8-thread oracle already sits 6.3e-4
 # from the single-threaded reference fixture (tools/knife_edge.py): the knife edge of the batch-2 fixture survives at batch 8
-# for this loss alone, so only g_loss gets the wider bound.
+# for this loss alone, so only g_loss gets the wider bound.  Measured on the device (profiles/r03_knife_edge_batch8_fixtures.txt): the step
+# has two states 5e-3 apart in g_loss (4e-5 apart in gp: one R1 LeakyReLU mask on its edge, amplified by D's Adam step); with 1e-7 input
+# noise the direct kernels land in the far one in 1 of 4 trials, the Winograd kernels (more accurate against float64, another
+# rounding pattern) in 3 of 4 -- the bound covers both states, d_loss / gp stay at 1e-4.
+# c256a3_cnn_b8: the same loss (g_loss after D's Adam step; d_loss / gp agree at 3e-6) moves between +6e-5 and -8.6e-4 over three runs
+# with 1e-7 input noise on the Winograd kernels (same file; 4.5e-5 on the direct ones): bound 1e-3 for g_loss alone.
 # c64a1_iqn_b64: gp (and d_loss, which contains it) moves in quanta with the rounding pattern -- LeakyReLU masks under R1 flipping: the
 # HIP trainer lands between 5e-7 and 1.8e-4 from the fixture over five runs with 1e-7 input noise, with the attention projections
 # fused or separate alike (tools/knife_edge_hip.py, profiles/r03_knife_edge_c64a1_iqn_b64.txt); the fixture's own images happen to
 # sit at +1.35e-4 with the fused kernels, +4.4e-5 with the separate ones.
-KNIFE_EDGE = {'c128a3_iqn_b4': 3e-4, 'c128a3_cnn_b256': {'g_loss': 2e-4}, 'c128big_cnn_b8': {'g_loss': 2e-3},
+KNIFE_EDGE = {'c128a3_iqn_b4': 3e-4, 'c128a3_cnn_b256': {'g_loss': 2e-4}, 'c128big_cnn_b8': {'g_loss': 8e-3}, 'c256a3_cnn_b8': {'g_loss': 1e-3},
               'c64a1_iqn_b64': {'gp': 3e-4, 'd_loss': 3e-4}}
 
 

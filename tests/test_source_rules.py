@@ -13,6 +13,7 @@ SCALAR_TOKEN = re.compile(r'^(i|v|wave|CT_THREADS|GB_T|PCHP|WCHP|GCHP|ACH|BCH|\d
 
 
 FID = os.path.join(os.path.dirname(HERE), 'tartangan_amd', 'csrc', 'fid.hip')
+WINO = os.path.join(os.path.dirname(HERE), 'tartangan_amd', 'csrc', 'wino.h')       # (included by conv.hip)
 
 
 def _guards(path=CONV):
@@ -34,7 +35,9 @@ def test_every_lds_dma_sits_under_a_scalar_condition_only():
     assert len(guards) >= 10                               # conv_dma, wgrad, upT, upfwd, s2 wgrad: two regions each
     fid = _guards(FID)
     assert len(fid) == 2                                   # gemm_big_kernel: the A and the B panel
-    for lineno, cond, stmt in guards + fid:
+    wino = _guards(WINO)
+    assert len(wino) == 1                                  # conv_wino_dma_kernel: the patch
+    for lineno, cond, stmt in guards + fid + wino:
         assert cond is not None, f'csrc line {lineno}: unguarded or unparsable dma16 call: {stmt}'
         assert 'threadIdx' not in cond and 'lane' not in cond, f'csrc line {lineno}: per-lane guard on an LDS-DMA: {cond}'
         for tok in re.findall(r'[A-Za-z_]\w*|\d+', cond):
@@ -45,6 +48,7 @@ def test_wave_index_is_scalar_where_it_guards_a_dma():
     src = open(CONV).read()
     assert '__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)' in src
     # every kernel that issues DMAs takes `wave` from wave_index(), not from threadIdx directly
+    src = src + open(WINO).read()
     for m in re.finditer(r'__global__[^{]*?(\w+_dma_kernel)\(', src):
         body = src[m.end():src.index('\n}\n', m.end())]
         assert 'wave = wave_index()' in body, f'{m.group(1)}: wave must be the scalar wave_index()'
