@@ -195,7 +195,7 @@ def hbm_traffic_per_launch(a):
     """HBM bytes per launch of the conv fwd/dgrad family from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes over this same command, tools/pmc_traffic.sh, corrected as the MI355X guide prescribes).  Counters
     cannot be collected from inside the timed process, so the figure comes from that file -- and only if the file was
-    measured on the kernel source this process runs (sha256 of csrc/conv.hip stamped into it) and on this workload;
+    measured on the kernel source this process runs (sha256 of csrc/conv.hip + csrc/wino.h stamped into it) and on this workload;
     otherwise null, with the reason beside it.  -> (bytes or None, provenance dict)"""
     import hashlib
     import subprocess
@@ -204,7 +204,7 @@ def hbm_traffic_per_launch(a):
     with open(TRAFFIC_FILE) as f:
         k = json.load(f)
     here = os.path.dirname(os.path.abspath(__file__))
-    sha = hashlib.sha256(open(os.path.join(here, 'tartangan_amd', 'csrc', 'conv.hip'), 'rb').read()).hexdigest()
+    sha = hashlib.sha256(b''.join(open(os.path.join(here, 'tartangan_amd', 'csrc', f), 'rb').read() for f in ('conv.hip', 'wino.h'))).hexdigest()
     try:
         blob = subprocess.run(['git', 'hash-object', TRAFFIC_FILE], capture_output=True, text=True, cwd=here).stdout.strip()
     except Exception:
@@ -212,7 +212,7 @@ def hbm_traffic_per_launch(a):
     prov = {'traffic_source': 'profiles/r03_hbm_traffic.json', 'traffic_file_git_blob': blob or None,
             'traffic_measured_on_conv_hip_sha256': k.get('conv_hip_sha256', '')[:16], 'conv_hip_sha256': sha[:16]}
     if k.get('conv_hip_sha256') != sha:
-        prov['traffic_note'] = 'stale: csrc/conv.hip changed since the counters were collected'
+        prov['traffic_note'] = 'stale: csrc/conv.hip / wino.h changed since the counters were collected'
         return None, prov
     if not (a.config == '128:3' and a.trainer == 'cnn' and a.batch == 64):
         prov['traffic_note'] = 'measured on the default workload only'
@@ -222,9 +222,10 @@ def hbm_traffic_per_launch(a):
 
 # the MFMA convolution kernels that produce activations / activation gradients: C-ABI entry point -> kernel name in the
 # PMC summary.  (The stride-2 kernels serve the generator's up-convs and the discriminator's pooled convs.)
-CONV_FAMILY = {'conv2d_fwd': 'conv_dma_kernel / conv_fwd_kernel (fwd)', 'conv2d_dgrad': 'conv_dma_kernel / conv_fwd_kernel (dgrad)',
+CONV_FAMILY = {'conv2d_fwd': 'conv_wino_dma_kernel / conv_dma_kernel / conv_fwd_kernel (fwd)',
+               'conv2d_dgrad': 'conv_wino_dma_kernel / conv_dma_kernel / conv_fwd_kernel (dgrad)',
                'upconv3x3_fwd': 'conv_upfwd_dma_kernel', 'poolconv3x3_dgrad': 'conv_upfwd_dma_kernel',
-               'upconv3x3_dgrad': 'conv_upT_dma_kernel', 'poolconv3x3_fwd': 'conv_upT_dma_kernel'}
+               'upconv3x3_dgrad': 'conv_poolwino_dma_kernel / conv_upT_dma_kernel', 'poolconv3x3_fwd': 'conv_poolwino_dma_kernel / conv_upT_dma_kernel'}
 
 
 def _cpu_sample(config, kind, batch, threads, n):
@@ -440,8 +441,10 @@ def main():
             conv = {k: sum(agg[n][k] for n in CONV_FAMILY if n in agg) for k in ('ms', 'launches', 'flops', 'bytes')}
             traffic, traffic_prov = hbm_traffic_per_launch(a)
             ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA implicit-GEMM 3x3 / stride-2 conv family (activations and activation gradients): '
-                                                          'conv_dma_kernel (fwd + dgrad), conv_upfwd_dma_kernel, conv_upT_dma_kernel',
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA 3x3 / stride-2 conv family (activations and activation gradients): '
+                                                          'conv_wino_dma_kernel (Winograd F(2x2,3x3), fwd + dgrad), conv_dma_kernel, '
+                                                          'conv_upfwd_dma_kernel, conv_poolwino_dma_kernel (9-frequency pooled form), conv_upT_dma_kernel',
+                               'flops': 'algorithmic (direct-form multiply-adds of the layer); the Winograd kernels issue 2.25x / 1.78x fewer',
                                'achieved': round(ach, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                                'traffic': traffic, **traffic_prov,

@@ -12,7 +12,7 @@ print(f'steps profiled {nsteps:.0f}  GPU-busy ms/step {tot / nsteps / 1e6:.3f}  
 fam = collections.defaultdict(float)
 for r in rows:
     n = short(r['Name'])
-    key = ('conv fwd/dgrad' if re.match(r'conv_(dma|fwd|upfwd|upT|upfwd_dma|upT_dma)_kernel|conv1x1', n) else
+    key = ('conv fwd/dgrad' if re.match(r'conv_(dma|fwd|upfwd|upT|upfwd_dma|upT_dma|wino_dma|poolwino_dma)_kernel|conv1x1', n) else
            'conv wgrad' if 'wgrad' in n else 'batchnorm' if re.match(r'planes::|bn_|chan_stage', n) else
            'attention' if n.startswith('attn') else 'aten' if n.startswith('at::') else 'other')
     fam[key] += float(r['TotalDurationNs']) / nsteps / 1e6

@@ -22,6 +22,8 @@ def load(d, counter):
                 fam += ' (dgrad)' if re.search(r', true>$', n) else ' (fwd)'
             elif fam == 'conv_dma_kernel':
                 fam += ' (dgrad)' if re.search(r', true, (true|false)>$', n) else ' (fwd)'
+            elif fam == 'conv_wino_dma_kernel':
+                fam += ' (dgrad)' if re.search(r', true(, \d+)?>$', n) else ' (fwd)'
             agg[fam][0] += 1
             agg[fam][1] += float(r['Counter_Value'])
     return agg
@@ -39,10 +41,11 @@ for fam in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, [0, 0])[
                 'hbm_bytes_per_launch': round(rd + wr)}
 import hashlib, os
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sha = hashlib.sha256(open(os.path.join(here, 'tartangan_amd', 'csrc', 'conv.hip'), 'rb').read()).hexdigest()
+sha = hashlib.sha256(b''.join(open(os.path.join(here, 'tartangan_amd', 'csrc', f), 'rb').read() for f in ('conv.hip', 'wino.h'))).hexdigest()
 # the roofline family of bench.py: every kernel that produces activations / activation gradients of a 3x3 or stride-2 conv
 FAMILY = ('conv_fwd_kernel (fwd)', 'conv_fwd_kernel (dgrad)', 'conv_dma_kernel (fwd)', 'conv_dma_kernel (dgrad)', 'conv_upfwd_kernel',
-          'conv_upT_kernel', 'conv_upfwd_dma_kernel', 'conv_upT_dma_kernel')          # (1x1 kernels: priced against HBM, listed apart)
+          'conv_upT_kernel', 'conv_upfwd_dma_kernel', 'conv_upT_dma_kernel', 'conv_wino_dma_kernel (fwd)', 'conv_wino_dma_kernel (dgrad)',
+          'conv_poolwino_dma_kernel')          # (1x1 kernels: priced against HBM, listed apart)
 fl = sum(out[k]['launches_sampled'] for k in FAMILY if k in out)
 fb = sum(out[k]['launches_sampled'] * out[k]['hbm_bytes_per_launch'] for k in FAMILY if k in out)
 family = {'kernels': [k for k in FAMILY if k in out], 'launches_sampled': fl, 'hbm_bytes_per_launch': round(fb / max(fl, 1))}
