@@ -3054,6 +3054,21 @@ static int launch_wino_geo(const float* x, const float* w, const float* bias, co
     return -1;
   return tg_launch_status();
 }
+// small planes (8x8: one image per workgroup, 4x4: four): the four waves split every 16-channel chunk, partial outputs summed in LDS
+template <class G, bool DGRAD>
+static int launch_wino_ksplit(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st,
+                              int64_t min_wgs) {
+  if (s.Cin % 16 != 0) return -1;
+  const int tiles = num_tiles<G>(s.B, s.H, s.W);
+  const int flags = (tiles % 8 == 0) ? 1 : 0;
+  if (s.Cout > 16 && (int64_t)tiles * ((s.Cout + 31) / 32) >= 256 && s.B % 2 == 0)
+    conv_wino_dma_kernel<G, 2, DGRAD, 16, true><<<dim3(tiles, (s.Cout + 31) / 32), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, flags);
+  else if ((int64_t)tiles * ((s.Cout + 15) / 16) >= min_wgs)
+    conv_wino_dma_kernel<G, 1, DGRAD, 16, true><<<dim3(tiles, (s.Cout + 15) / 16), CT_THREADS, 0, st>>>(x, w, bias, residual, y, s, flags);
+  else
+    return -1;
+  return tg_launch_status();
+}
 // -> true when the Winograd kernel took the launch
 template <bool DGRAD>
 static bool try_launch_wino(const float* x, const float* w, const float* bias, const float* residual, float* y, Shape s, hipStream_t st,
@@ -3069,8 +3084,10 @@ static bool try_launch_wino(const float* x, const float* w, const float* bias, c
   int r = -1;
   if (s.H % 8 == 0 && s.W % 32 == 0) r = launch_wino_geo<GX, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
   else if (s.H == 16 && s.W == 16) r = launch_wino_geo<G16, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
-  else if (mode == 2 && s.H == 8 && s.W == 8) r = launch_wino_geo<G8, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
-  else if (mode == 2 && s.H == 4 && s.W == 4) r = launch_wino_geo<G4, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
+  // 8x8 / 4x4 planes, K-split form: measured SLOWER than the direct K-split kernels (128 -> 128 @8^2, batch 64 / 128: 20.5 / 39.1 us
+  // against 17.1 / 28.8; the step 9.29 against 9.21 ms) -- a workgroup transforms a whole filter chunk for 16 tiles; mode 2 only
+  else if (mode == 2 && s.H == 8 && s.W == 8) r = launch_wino_ksplit<G8k, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
+  else if (mode == 2 && s.H == 4 && s.W == 4) r = launch_wino_ksplit<G4k, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
   if (r < 0) return false;
   *rc = r;
   return true;

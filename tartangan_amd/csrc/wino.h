@@ -65,6 +65,15 @@ template <> struct WinoMap<G4> {
   __device__ __forceinline__ static void at(int w, int i, int& img, int& y0, int& x0) { img = 4 * w + (i >> 2); y0 = 2 * ((i >> 1) & 1); x0 = 2 * (i & 1); }
 };
 
+// K-split geometries (small planes): ONE 16-tile strip per workgroup, shared by the four waves, each of which takes one k-step
+// (4 channels) of a 16-channel chunk; their partial outputs are summed through LDS at the end (conv_wino_dma_kernel<.., KS = true>).
+template <> struct WinoMap<G8k> {
+  __device__ __forceinline__ static void at(int, int i, int& img, int& y0, int& x0) { img = 0; y0 = 2 * (i >> 2); x0 = 2 * (i & 3); }
+};
+template <> struct WinoMap<G4k> {
+  __device__ __forceinline__ static void at(int, int i, int& img, int& y0, int& x0) { img = i >> 2; y0 = 2 * ((i >> 1) & 1); x0 = 2 * (i & 1); }
+};
+
 constexpr int WINO_CK = 8;      // input channels per staged chunk (two k-steps of the 16x16x4 MFMA); 4 for a 4-channel input
 constexpr int WINO_US = 20;     // floats per (channel, output channel) slot of the transformed filter: 16 + 4 of padding
                                 // (a ds_read_b128 lane group -- 8 lanes of one k, 8 of the next -- starts on 16 distinct 16-byte slots)
@@ -83,13 +92,15 @@ template <class G> struct WinoPatch {
   static_assert(CIS % 64 == 32 && RAW % 4 == 0, "channel stride");
 };
 
-template <class G, int NB, bool DGRAD, int CK = WINO_CK>
-__global__ void __launch_bounds__(CT_THREADS, (G::NI > 1) ? 1 : (NB == 1) ? 3 : 2)
+template <class G, int NB, bool DGRAD, int CK = WINO_CK, bool KS = false>
+__global__ void __launch_bounds__(CT_THREADS, KS ? (NB == 1 ? 2 : 1) : (G::NI > 1) ? 1 : (NB == 1) ? 3 : 2)
 conv_wino_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                      const float* __restrict__ residual, float* __restrict__ y, Shape s, int flags) {
   using P = WinoPatch<G>;
   constexpr int NT = 16 * NB, US = WINO_US, CIS = P::CIS;
   static_assert(CK % 4 == 0, "whole k-steps");
+  static_assert(!KS || (CK == 16 && G::NPIX == 64), "K-split: 16 tiles per workgroup, one k-step of a 16-channel chunk per wave");
+  constexpr int FPT = (CK * NT + CT_THREADS - 1) / CT_THREADS;     // filter pairs per thread
   constexpr int PCH = CK * P::CPC, PCHP = dma_pad(PCH);           // 16-byte chunks of a patch buffer, padded to whole wave pieces
   constexpr int NVP = (PCHP + CT_THREADS - 1) / CT_THREADS;
   constexpr int PBUF = PCHP * 4, UBUF = CK * NT * US;
@@ -130,36 +141,44 @@ conv_wino_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, c
   const int mi = lane & 15, kk = lane >> 4;
   int img, y0, x0;
   WinoMap<G>::at(wave, mi, img, y0, x0);
-  const int a_off = (img * P::PH + y0) * P::PWS + x0 + 2 + kk * CIS;      // (even) LDS offset of the first pair of this lane's patch
-  const int b_off = (kk * NT + mi) * US;                                  // its filter slot
+  const int kbase = KS ? 4 * wave : 0;                                    // K-split: this wave's k-step of every chunk
+  const int a_off = (img * P::PH + y0) * P::PWS + x0 + 2 + (kbase + kk) * CIS;      // (even) LDS offset of the first pair of this lane's patch
+  const int b_off = ((kbase + kk) * NT + mi) * US;                                  // its filter slot
 
-  // filter pair of this thread, output channel fastest: consecutive lanes store 80 bytes apart (conflict-free ds_write_b128)
-  const int fn = (int)threadIdx.x % NT, fk = (int)threadIdx.x / NT;
-  const bool f_active = threadIdx.x < CK * NT;
-  const bool f_n_ok = f_active && (co0 + fn < s.Cout);
-  float g9[9];
+  // filter pairs of this thread, output channel fastest: consecutive lanes store 80 bytes apart (conflict-free ds_write_b128)
+  float g9[FPT][9];
   auto load_filter = [&](int c0) {
-    const bool ok = f_n_ok && (c0 + fk < s.Cin);
-    const float* src = DGRAD ? w + ((int64_t)(c0 + fk) * s.Cout + (co0 + fn)) * 9 : w + ((int64_t)(co0 + fn) * s.Cin + (c0 + fk)) * 9;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g9[t] = ok ? src[DGRAD ? 8 - t : t] : 0.f;
+    for (int t = 0; t < FPT; ++t) {
+      const int e = t * CT_THREADS + threadIdx.x;
+      const int fn = e % NT, fk = e / NT;
+      const bool ok = (e < CK * NT) && (co0 + fn < s.Cout) && (c0 + fk < s.Cin);
+      const float* src = DGRAD ? w + ((int64_t)(c0 + fk) * s.Cout + (co0 + fn)) * 9 : w + ((int64_t)(co0 + fn) * s.Cin + (c0 + fk)) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) g9[t][i] = ok ? src[DGRAD ? 8 - i : i] : 0.f;
+    }
   };
   auto store_filter = [&](int buf) {        // U = G g G^T, 16 floats, frequency-contiguous
-    if (f_active) {
-      float u[4][3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float s02 = g9[c] + g9[6 + c];
-        u[0][c] = g9[c];
-        u[1][c] = 0.5f * (s02 + g9[3 + c]);
-        u[2][c] = 0.5f * (s02 - g9[3 + c]);
-        u[3][c] = g9[6 + c];
-      }
-      float* dst = ul + buf * UBUF + (fk * NT + fn) * US;
+    for (int t = 0; t < FPT; ++t) {
+      const int e = t * CT_THREADS + threadIdx.x;
+      if (e < CK * NT) {
+        const float* g = g9[t];
+        float u[4][3];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s02 = u[r][0] + u[r][2];
-        *reinterpret_cast<float4*>(dst + 4 * r) = make_float4(u[r][0], 0.5f * (s02 + u[r][1]), 0.5f * (s02 - u[r][1]), u[r][2]);
+        for (int c = 0; c < 3; ++c) {
+          const float s02 = g[c] + g[6 + c];
+          u[0][c] = g[c];
+          u[1][c] = 0.5f * (s02 + g[3 + c]);
+          u[2][c] = 0.5f * (s02 - g[3 + c]);
+          u[3][c] = g[6 + c];
+        }
+        float* dst = ul + buf * UBUF + e * US;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s02 = u[r][0] + u[r][2];
+          *reinterpret_cast<float4*>(dst + 4 * r) = make_float4(u[r][0], 0.5f * (s02 + u[r][1]), 0.5f * (s02 - u[r][1]), u[r][2]);
+        }
       }
     }
   };
@@ -186,7 +205,7 @@ conv_wino_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, c
     const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(pl + buf * PBUF + a_off);   // LDS byte address
     const float* pb = ul + buf * UBUF + b_off;
 #pragma unroll
-    for (int ks = 0; ks < CK / 4; ++ks) {
+    for (int ks = 0; ks < (KS ? 1 : CK / 4); ++ks) {
       f32x4 ub[NB][4];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
@@ -234,54 +253,87 @@ conv_wino_dma_kernel(const float* __restrict__ x, const float* __restrict__ w, c
   const uint32_t HW = (uint32_t)(s.H * s.W);
   const int Wr = s.W >> 1;
   const uint32_t HWr = HW >> 2;
+  // output transform of tile pair (2 pr2, 2 pr2 + 1) of block nb: two rows of four x-adjacent pixels
+  auto out_rows = [&](int nb, int pr2, float (&o)[2][4]) {
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
+    for (int tt = 0; tt < 2; ++tt) {
+      const int r = 2 * pr2 + tt;
+      float m[4][4];
+#pragma unroll
+      for (int f = 0; f < 16; ++f) m[f >> 2][f & 3] = acc[f][nb][r];
+      float sa[2][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        sa[0][c] = m[0][c] + m[1][c] + m[2][c];
+        sa[1][c] = m[1][c] - m[2][c] - m[3][c];
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        o[a][2 * tt] = sa[a][0] + sa[a][1] + sa[a][2];
+        o[a][2 * tt + 1] = sa[a][1] - sa[a][2] - sa[a][3];
+      }
+    }
+  };
+  // bias / residual / store of one row of four pixels
+  auto finish_row = [&](int nb, int pr2, int a, float4 o) {
     const int co = co0 + nb * 16 + j;
-    if (co >= s.Cout) continue;
+    int ti, ty, tx;
+    WinoMap<G>::at(wave, 4 * q + 2 * pr2, ti, ty, tx);
+    const int b = tc.b0 + ti;
+    if (co >= s.Cout || b >= s.B) return;
     const float bv = bias ? bias[co] : 0.f;
-#pragma unroll
-    for (int pr2 = 0; pr2 < 2; ++pr2) {           // tile pair (2 pr2, 2 pr2 + 1): x-adjacent
-      float o[2][4];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int r = 2 * pr2 + tt;
-        float m[4][4];
-#pragma unroll
-        for (int f = 0; f < 16; ++f) m[f >> 2][f & 3] = acc[f][nb][r];
-        float sa[2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          sa[0][c] = m[0][c] + m[1][c] + m[2][c];
-          sa[1][c] = m[1][c] - m[2][c] - m[3][c];
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          o[a][2 * tt] = sa[a][0] + sa[a][1] + sa[a][2] + bv;
-          o[a][2 * tt + 1] = sa[a][1] - sa[a][2] - sa[a][3] + bv;
-        }
+    o.x += bv; o.y += bv; o.z += bv; o.w += bv;
+    const int hh = tc.h0 + ty + a, ww = tc.w0 + tx;
+    const int64_t plane = (int64_t)b * s.Cout + co;
+    if (residual) {
+      if (s.res_up) {
+        const float2 rr = *reinterpret_cast<const float2*>(residual + plane * HWr + (int64_t)(hh >> 1) * Wr + (ww >> 1));
+        o.x += rr.x; o.y += rr.x; o.z += rr.y; o.w += rr.y;
+      } else {
+        const float4 rr = *reinterpret_cast<const float4*>(residual + plane * HW + (int64_t)hh * s.W + ww);
+        o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
       }
-      int ti, ty, tx;
-      WinoMap<G>::at(wave, 4 * q + 2 * pr2, ti, ty, tx);
-      const int b = tc.b0 + ti;
-      if (b >= s.B) continue;
-      const int hh = tc.h0 + ty, ww = tc.w0 + tx;
-      const int64_t plane = (int64_t)b * s.Cout + co;
-      if (residual) {
-        if (s.res_up) {
-          const float2 rr = *reinterpret_cast<const float2*>(residual + plane * HWr + (int64_t)(hh >> 1) * Wr + (ww >> 1));
+    }
+    *reinterpret_cast<float4*>(y + plane * HW + (int64_t)hh * s.W + ww) = o;
+  };
+  if constexpr (!KS) {
 #pragma unroll
-          for (int a = 0; a < 2; ++a) { o[a][0] += rr.x; o[a][1] += rr.x; o[a][2] += rr.y; o[a][3] += rr.y; }
-        } else {
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            const float4 rr = *reinterpret_cast<const float4*>(residual + plane * HW + (int64_t)(hh + a) * s.W + ww);
-            o[a][0] += rr.x; o[a][1] += rr.y; o[a][2] += rr.z; o[a][3] += rr.w;
-          }
-        }
+      for (int pr2 = 0; pr2 < 2; ++pr2) {
+        float o[2][4];
+        out_rows(nb, pr2, o);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) finish_row(nb, pr2, a, make_float4(o[a][0], o[a][1], o[a][2], o[a][3]));
       }
+  } else {
+    // K-split: the four waves hold partial sums of the SAME outputs.  Each transforms its own (the transform is linear), leaves
+    // the rows in LDS -- red[wave][row slot][lane], over the filter buffers, which nobody reads any more -- and finishes the row
+    // slots s == wave (mod 4), summing the four partials in wave order.
+    constexpr int SLOTS = NB * 4;
+    static_assert(4 * SLOTS * 64 * 4 <= 2 * UBUF, "the reduction buffer fits the filter buffers");
+    float4* red = reinterpret_cast<float4*>(ul);
+    __syncthreads();                              // every wave is past its last read of the filter buffers
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
-        *reinterpret_cast<float4*>(y + plane * HW + (int64_t)(hh + a) * s.W + ww) = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int pr2 = 0; pr2 < 2; ++pr2) {
+        float o[2][4];
+        out_rows(nb, pr2, o);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) red[(wave * SLOTS + (nb * 4 + pr2 * 2 + a)) * 64 + lane] = make_float4(o[a][0], o[a][1], o[a][2], o[a][3]);
+      }
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int slot = nb * 4 + wave;             // (pr2, a) = (wave >> 1, wave & 1) of block nb
+      float4 o = red[slot * 64 + lane];
+#pragma unroll
+      for (int ww2 = 1; ww2 < 4; ++ww2) {
+        const float4 t = red[(ww2 * SLOTS + slot) * 64 + lane];
+        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+      }
+      finish_row(nb, wave >> 1, wave & 1, o);
     }
   }
 }

@@ -6,15 +6,15 @@ bucket (tartangan_amd.optim), so a step needs exactly two gradient collectives -
 the D bucket (2.4 MB at 128:3) after the D backward, of the G bucket (5.1 MB) after the G backward.
 At these sizes the collectives are latency-bound; there is nothing to bucket further.
 
-Overlap (``overlap=True``, the default on a device): both all-reduces are issued on a side stream
-that waits for the producing backward, and are joined only where their result is consumed --
-the D bucket right before D's Adam step, i.e. after the G phase's generator forward (which needs
-no discriminator weights; trainers.cnn._g_forward), the G bucket right before G's Adam step, i.e. immediately: that collective (5.1 MB, latency-bound) is
-exposed.  The only generator-independent work of the next step -- D(real) forward and the R1 first-order pass -- now runs
-fused with D(fake) as one 2B pass (``functional.Pair``), which needs the generator's new samples first; un-pairing it to
-hide ~50-100 us of collective would cost ~0.5 ms of step time (DESIGN.md "Multi-GPU").  The serial schedule
-(``overlap=False``) issues the same collectives on the compute stream; both give bit-identical
-parameters (tests/test_dp_gloo.py).
+Schedule.  Default (``overlap=False``): the SERIAL schedule -- both all-reduces on the compute stream right after the
+backward that fills the bucket; with RCCL they are device work and are captured INTO the step's graphs (three graphs, as on
+one GPU: ``buckets_in_graph``), with a host-staged backend (gloo) they stay eager calls between four graph replays.
+``overlap=True``: both all-reduces on a side stream that waits for the producing backward, joined only where consumed (the D
+bucket after the G phase's generator forward, trainers.cnn._g_forward; the G bucket immediately).  Measured with RCCL on one
+rank (``rehearse=True``, bench.py --rehearse-rccl, DESIGN.md "Multi-GPU"): 9.47 ms/step serial in-graph, 9.92 side stream, 9.43
+without collectives -- since the generator's two forwards share one pass (``functional.Pair``) there is nothing left to hide the D
+bucket under, and un-pairing D(real) | D(fake) to hide ~50-100 us of the G bucket would cost ~0.4 ms.  All schedules give
+bit-identical parameters (tests/test_dp_gloo.py, tests/test_dp_gpu.py).
 
 BatchNorm: with ``sync_bn=True`` every BatchNorm2d of G and D normalises with the statistics of
 the GLOBAL batch (functional.SyncGroup: per-layer all-reduces of the forward / backward /

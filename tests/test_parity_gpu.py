@@ -32,7 +32,8 @@ def hip_backend():
 # every D weight moved by lr * sign(gradient), sign decided by rounding where the gradient is ~0 -- moves by up to 6.9e-5 in the
 # reference's own arithmetic under a 1e-7 input perturbation (tools/knife_edge.py, 3 trials, all to the same side); one GPU
 # lands 1.2e-4 away, four ranks with SyncBN (tests/test_dp_gpu.py, same bound) between 0.9e-4 and 1.1e-4 depending on the
-# summation order inside the attention kernels.
+# summation order inside the attention kernels; with the Winograd convolutions (round 3; more accurate against float64 than the direct
+# kernels, tools/wino_accuracy.py, but another rounding pattern) the four-rank run lands 2.4e-4 away, d_loss / gp still at 5e-6: bound 4e-4.
 # c128big_cnn_b8 (1024-channel layers): d_loss and gp agree at 1e-6, but g_loss = 0.0107 (a saturated discriminator, taken after
 # D's Adam step) spans 7.6e-4 relative over six oracle runs with 1e-7 input noise, and the 8-thread oracle already sits 6.3e-4
 # from the single-threaded reference fixture (tools/knife_edge.py): the knife edge of the batch-2 fixture survives at batch 8
@@ -46,7 +47,7 @@ def hip_backend():
 # HIP trainer lands between 5e-7 and 1.8e-4 from the fixture over five runs with 1e-7 input noise, with the attention projections
 # fused or separate alike (tools/knife_edge_hip.py, profiles/r03_knife_edge_c64a1_iqn_b64.txt); the fixture's own images happen to
 # sit at +1.35e-4 with the fused kernels, +4.4e-5 with the separate ones.
-KNIFE_EDGE = {'c128a3_iqn_b4': 3e-4, 'c128a3_cnn_b256': {'g_loss': 2e-4}, 'c128big_cnn_b8': {'g_loss': 8e-3}, 'c256a3_cnn_b8': {'g_loss': 1e-3},
+KNIFE_EDGE = {'c128a3_iqn_b4': 3e-4, 'c128a3_cnn_b256': {'g_loss': 4e-4}, 'c128big_cnn_b8': {'g_loss': 8e-3}, 'c256a3_cnn_b8': {'g_loss': 1e-3},
               'c64a1_iqn_b64': {'gp': 3e-4, 'd_loss': 3e-4}}
 
 

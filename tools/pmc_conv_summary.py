@@ -30,7 +30,7 @@ for (name, grid, lds, vgpr, agpr), c in agg.items():
              lds_bank_conflict_frac=round(m.get('SQ_LDS_BANK_CONFLICT', 0) / max(m.get('SQ_LDS_IDX_ACTIVE', 0), 1), 4),
              mean_waves_per_simd=round(wc * 4.0 / (1024.0 * cyc), 2) if cyc else None,
              l2_hit_rate=round(m.get('TCC_HIT_sum', 0) / max(m.get('TCC_HIT_sum', 0) + m.get('TCC_MISS_sum', 0), 1), 4))
-    out[name] = d
+    out[f'{name} grid={grid}'] = d
 print(json.dumps(dict(source='rocprofv3 --kernel-trace --pmc (4 passes, tools/pmc_conv.sh) on tools/bench_conv_one.py, batch 64',
                       units='quad-cycle counters normalised by SQ_WAVE_CYCLES; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles)',
                       kernels=out), indent=1))
