@@ -10,8 +10,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-KNOBS = [{}, {'TG_DMA_TILE': '512'}, {'TG_DMA_TILE': '512', 'TG_DMA_CK': '4'}, {'TG_DMA_DB': '0'}, {'TG_DMA_CK': '4'}, {'TG_DMA_CK': '8'},
-         {'TG_DMA_PRIO': '1'}, {'TG_DMA_WGRAD_DB': '1'}, {'TG_DMA_S2': '0'}, {'TG_DMA_WGRAD': '0'}, {'TG_DMA_KSPLIT': '0'}, {'TG_CONV_DMA': '0'}]
+# The Winograd kernels (TG_CONV_WINO, default 1) take the stride-1 3x3 launches that fill the chip and the >= 32-channel pooled
+# convolutions; the direct kernels behind them -- what every TG_DMA_* knob selects among -- run with TG_CONV_WINO=0.
+_DIRECT = [{'TG_DMA_TILE': '512'}, {'TG_DMA_TILE': '512', 'TG_DMA_CK': '4'}, {'TG_DMA_DB': '0'}, {'TG_DMA_CK': '4'}, {'TG_DMA_CK': '8'},
+           {'TG_DMA_PRIO': '1'}, {'TG_DMA_WGRAD_DB': '1'}, {'TG_DMA_S2': '0'}, {'TG_DMA_WGRAD': '0'}, {'TG_DMA_KSPLIT': '0'}, {'TG_CONV_DMA': '0'}]
+KNOBS = [{}, {'TG_CONV_WINO': '0'}, {'TG_CONV_WINO': '2'}] + [dict(k, TG_CONV_WINO='0') for k in _DIRECT]
 
 
 @pytest.mark.parametrize('knobs', KNOBS, ids=lambda k: ','.join(f'{a[3:]}={b}' for a, b in k.items()) or 'defaults')
