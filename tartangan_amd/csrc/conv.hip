@@ -3083,7 +3083,8 @@ static bool try_launch_wino(const float* x, const float* w, const float* bias, c
   // (64-tile workgroups on 8x8 / 4x4 planes give too few workgroups at the step's batch: mode 2 only)
   int r = -1;
   if (s.H % 8 == 0 && s.W % 32 == 0) r = launch_wino_geo<GX, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
-  else if (s.H == 16 && s.W == 16) r = launch_wino_geo<G16, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
+  // (16x16 planes at batch 64 -- exactly one workgroup per CU -- measured neutral to slightly slower inside the step: from two per CU)
+  else if (s.H == 16 && s.W == 16) r = launch_wino_geo<G16, DGRAD>(x, w, bias, residual, y, s, st, mode == 2 ? 1 : 512);
   // 8x8 / 4x4 planes, K-split form: measured SLOWER than the direct K-split kernels (128 -> 128 @8^2, batch 64 / 128: 20.5 / 39.1 us
   // against 17.1 / 28.8; the step 9.29 against 9.21 ms) -- a workgroup transforms a whole filter chunk for 16 tiles; mode 2 only
   else if (mode == 2 && s.H == 8 && s.W == 8) r = launch_wino_ksplit<G8k, DGRAD>(x, w, bias, residual, y, s, st, min_wgs);
