@@ -36,7 +36,7 @@ def test_every_lds_dma_sits_under_a_scalar_condition_only():
     fid = _guards(FID)
     assert len(fid) == 2                                   # gemm_big_kernel: the A and the B panel
     wino = _guards(WINO)
-    assert len(wino) == 1                                  # conv_wino_dma_kernel: the patch
+    assert len(wino) == 2                                  # conv_wino_dma_kernel, conv_poolwino_dma_kernel: the patch
     for lineno, cond, stmt in guards + fid + wino:
         assert cond is not None, f'csrc line {lineno}: unguarded or unparsable dma16 call: {stmt}'
         assert 'threadIdx' not in cond and 'lane' not in cond, f'csrc line {lineno}: per-lane guard on an LDS-DMA: {cond}'
