@@ -23,7 +23,7 @@ def load(d, counter):
             elif fam == 'conv_dma_kernel':
                 fam += ' (dgrad)' if re.search(r', true, (true|false)>$', n) else ' (fwd)'
             elif fam == 'conv_wino_dma_kernel':
-                fam += ' (dgrad)' if re.search(r', true(, \d+)?>$', n) else ' (fwd)'
+                fam += ' (dgrad)' if re.search(r'conv_wino_dma_kernel<Geo<[^>]*>, \d+, true', n) else ' (fwd)'
             agg[fam][0] += 1
             agg[fam][1] += float(r['Counter_Value'])
     return agg
